@@ -1,0 +1,163 @@
+"""NumPy model of the DEVICE algorithm (not the oracle).
+
+This file restates, index for index, what the HIP kernels in
+old-audiosync_amd/csrc/ do, in float64 NumPy, so the decomposition
+(packed real FFT -> four-step complex FFT -> fused spectral combine -> inverse
+four-step) can be checked on the CPU against numpy.fft before any GPU time is
+spent.  It is test infrastructure only.
+
+Notation (same as csrc/xcorr_kernels.hip):
+  N   sample_len            F   real FFT length (even; F = 2N in the normal case)
+  M   F/2 complex length    M = M1*M2   j = j1*M2 + j2   k = k1 + M1*k2
+  layout of every intermediate: row-major [M1][M2]
+"""
+import numpy as np
+
+
+def tw(F, p):
+    """w_F^p = exp(-2*pi*i*p/F)"""
+    return np.exp(-2j * np.pi * (np.asarray(p) % F) / F)
+
+
+def fwd_cols(z, M1, M2):
+    """kernel 1: DFT over j1 for every column j2, then twiddle w_M^(j2*k1).
+    in : z[j1][j2]   out: A[k1][j2]"""
+    M = M1 * M2
+    a = np.fft.fft(z.reshape(M1, M2), axis=0)
+    k1 = np.arange(M1)[:, None]
+    j2 = np.arange(M2)[None, :]
+    return a * tw(M, k1 * j2)
+
+
+def fwd_rows(a):
+    """first half of kernel 2: DFT over j2 of each row k1 -> Z[k1 + M1*k2] at [k1][k2]"""
+    return np.fft.fft(a, axis=1)
+
+
+def combine(Zx, Zy, M1, M2):
+    """middle of kernel 2: from the permuted spectra of the two packed
+    sequences build G (the packed spectrum of the inverse real transform),
+    in the same permuted layout.  Mirrors the per-pair device code."""
+    M = M1 * M2
+    F = 2 * M
+    G = np.zeros((M1, M2), dtype=complex)
+
+    def pair(ax, bx, ay, by, k):
+        # ax = Zx[k], bx = Zx[M-k], same for y.  returns G[k], G[M-k]
+        w = tw(F, k)
+        Ex = 0.5 * (ax + np.conj(bx)); Ox = -0.5j * (ax - np.conj(bx))
+        Ey = 0.5 * (ay + np.conj(by)); Oy = -0.5j * (ay - np.conj(by))
+        Xk = Ex + w * Ox; Xm = np.conj(Ex - w * Ox)
+        Yk = Ey + w * Oy; Ym = np.conj(Ey - w * Oy)
+        Pk = Xk * np.conj(Yk); Pm = Xm * np.conj(Ym)
+        # inverse packing: G[k] = (P[k] + conj(P[M-k])) + i*conj(w^k)*(P[k] - conj(P[M-k]))
+        Gk = (Pk + np.conj(Pm)) + 1j * np.conj(w) * (Pk - np.conj(Pm))
+        # G[M-k]: w^(M-k) = -conj(w^k)  -> conj(w^(M-k)) = -w^k
+        Gm = (Pm + np.conj(Pk)) + 1j * (-w) * (Pm - np.conj(Pk))
+        return Gk, Gm
+
+    for k1 in range(M1):
+        m1 = (M1 - k1) % M1
+        if k1 > m1 and m1 != 0:
+            continue  # handled by the partner row
+        for k2 in range(M2):
+            k = k1 + M1 * k2
+            if k == 0:
+                z0x = Zx[0, 0]; z0y = Zx[0, 0] * 0 + Zy[0, 0]
+                X0 = z0x.real + z0x.imag; XM = z0x.real - z0x.imag
+                Y0 = z0y.real + z0y.imag; YM = z0y.real - z0y.imag
+                P0 = X0 * Y0; PM = XM * YM
+                G[0, 0] = (P0 + PM) + 1j * (P0 - PM)
+                continue
+            if k1 == 0:
+                m2 = M2 - k2
+            else:
+                m2 = M2 - 1 - k2
+            km = m1 + M1 * m2
+            assert km == M - k
+            if m1 == k1 and km < k:
+                continue  # self-paired row: each pair once
+            Gk, Gm = pair(Zx[k1, k2], Zx[m1, m2], Zy[k1, k2], Zy[m1, m2], k)
+            G[k1, k2] = Gk
+            if km != k:
+                G[m1, m2] = Gm
+    return G
+
+
+def inv_rows(G, M1, M2):
+    """end of kernel 2: inverse DFT over k2 of each row k1, then twiddle conj(w_M^(k1*j2)).
+    in: G[k1][k2]  out: B[k1][j2]"""
+    M = M1 * M2
+    b = np.fft.ifft(G, axis=1) * M2  # unnormalised
+    k1 = np.arange(M1)[:, None]
+    j2 = np.arange(M2)[None, :]
+    return b * np.conj(tw(M, k1 * j2))
+
+
+def inv_cols(B, M1, M2):
+    """kernel 3: inverse DFT over k1 of each column -> g[j1*M2 + j2] at [j1][j2];
+    r[2j] = Re g[j], r[2j+1] = Im g[j]"""
+    g = np.fft.ifft(B, axis=0) * M1
+    g = g.reshape(-1)
+    r = np.empty(2 * g.size)
+    r[0::2] = g.real
+    r[1::2] = g.imag
+    return r
+
+
+def embed_params(N, smooth_even_at_least):
+    """F selection: F = 2N when 2N is {2,3,5}-smooth, else the smallest
+    smooth even F >= 3N-1 with the source extended periodically (no wrap)."""
+    F = 2 * N
+    if is_smooth(F):
+        return F, 2 * N
+    return smooth_even_at_least(3 * N - 1), 3 * N - 1
+
+
+def is_smooth(n):
+    for p in (2, 3, 5):
+        while n % p == 0:
+            n //= p
+    return n == 1
+
+
+def next_smooth_even(n):
+    n += n & 1
+    while not is_smooth(n):
+        n += 2
+    return n
+
+
+def device_xcorr(source, sample, M1=None, M2=None):
+    """whole device pipeline -> r[0..2N)"""
+    N = len(sample)
+    F, Ls = embed_params(N, next_smooth_even)
+    M = F // 2
+    if M1 is None:
+        M1, M2 = split(M)
+    assert M1 * M2 == M
+    s = np.zeros(F); idx = np.arange(Ls); s[:Ls] = np.asarray(source)[idx % (2 * N)]
+    t = np.zeros(F); t[:N] = sample
+    zx = s[0::2] + 1j * s[1::2]
+    zy = t[0::2] + 1j * t[1::2]
+    Zx = fwd_rows(fwd_cols(zx, M1, M2))
+    Zy = fwd_rows(fwd_cols(zy, M1, M2))
+    G = combine(Zx, Zy, M1, M2)
+    r = inv_cols(inv_rows(G, M1, M2), M1, M2)
+    return r[: 2 * N]
+
+
+def split(M):
+    best = (1, M)
+    for a in range(1, int(M ** 0.5) + 1):
+        if M % a == 0:
+            best = (a, M // a)
+    return best
+
+
+def reference_r(source, sample):
+    """the reference recipe (src/cross_correlation.c:159-239) with numpy.fft"""
+    N = len(sample)
+    t = np.zeros(2 * N); t[:N] = sample
+    X = np.fft.rfft(np.asarray(source, dtype=float)); Y = np.fft.rfft(t)
+    return np.fft.irfft(X * np.conj(Y), 2 * N) * (2 * N)
