@@ -1,0 +1,137 @@
+/* include/audiosync/xcorr_hip.h — the C-ABI of the MI355X (gfx950) layer.
+ *
+ * This is the drop-in boundary for ONE path of vidify/old-audiosync: the FFT
+ * cross-correlation of src/cross_correlation.c.  Plain C, plain pointers and
+ * sizes; no C++/torch types.  The library behind it (libaudiosync_hip.so) is
+ * hand-written HIP for gfx950 and has no CPU fallback: every entry point
+ * fails (-1 / NULL, message in asx_last_error()) when no HIP device works.
+ *
+ * What each entry point replaces in the reference (paths under /root/reference):
+ *
+ *   asx_xcorr_f64            the body of cross_correlation()
+ *                            src/cross_correlation.c:133-307, called from
+ *                            src/audiosync.c:246 and tests/test_cross_correlation.c:25..109.
+ *                            include/audiosync/cross_correlation.h:24-25 is the signature
+ *                            the host-side wrapper (host/cross_correlation.c) keeps.
+ *   asx_pearson_f64          pearson_coefficient(), src/cross_correlation.c:74-116,
+ *                            include/audiosync/cross_correlation.h:10-11
+ *   asx_plan_create/destroy  the per-call fftw_plan_dft_r2c_1d / _c2r_1d / fftw_alloc_*
+ *                            / fftw_free of src/cross_correlation.c:33-36,159,187-201,
+ *                            237-239,300-304, hoisted into a reusable object
+ *   asx_xcorr_batch_f32      many independent cross_correlation() calls on float32 data
+ *   asx_xcorr_batch_f32_dev  (BASELINE.json north_star: batched many-pair variant);
+ *                            no reference equivalent beyond a loop over :133-307
+ *   asx_synth_pairs_dev      synthetic 48 kHz mono float32 pairs for benchmarks
+ *                            (stands in for the producers src/ffmpeg_pipe.c:68-81)
+ *
+ * Return convention everywhere: 0 = ok, -1 = error (asx_last_error() says why).
+ * Per-pair result convention (the reference's, src/cross_correlation.c:140,276,298):
+ *   ret[i] = 0 on success, -1 when the Pearson coefficient is NaN (lag[i] and
+ *   coef[i] are still written, exactly as the reference leaves them).
+ */
+#ifndef AUDIOSYNC_XCORR_HIP_H
+#define AUDIOSYNC_XCORR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct asx_plan asx_plan;
+
+/* ---- library / device ------------------------------------------------- */
+
+/* Number of usable HIP devices (0 when there is none or the runtime fails). */
+int asx_device_count(void);
+/* Last error message of the calling thread ("" if none). Never NULL. */
+const char *asx_last_error(void);
+/* ABI version of this header (bumped on any signature change). */
+int asx_abi_version(void);
+
+/* ---- plans ------------------------------------------------------------ */
+
+/* A plan fixes sample_len (N frames; source is 2N frames) and owns twiddle
+ * tables, index tables and HBM workspaces for up to `max_batch` pairs per
+ * launch group (larger batches are processed in groups).  device < 0 means
+ * "the current HIP device".  Returns NULL on error.
+ * Supported N: any N >= 1 whose transform length splits into two factors that
+ * fit the LDS kernels (N up to about 4,000,000).  Lengths 2N that are not
+ * {2,3,5}-smooth are embedded in a longer smooth transform (same r[k]). */
+asx_plan *asx_plan_create(size_t sample_len, size_t max_batch, int device);
+/* Same, with the transform split forced: "M1xM2xT" (M1*M2 = F/2, T = tile
+ * columns, a power of two <= 64).  NULL or "" = automatic (or $ASX_SPLIT). */
+asx_plan *asx_plan_create_ex(size_t sample_len, size_t max_batch, int device, const char *split);
+void asx_plan_destroy(asx_plan *plan);
+
+/* Introspection (used by tests, bench and DESIGN.md's numbers). */
+size_t asx_plan_sample_len(const asx_plan *plan);
+size_t asx_plan_fft_len(const asx_plan *plan);        /* F, real transform length */
+int asx_plan_split(const asx_plan *plan, int *m1, int *m2, int *tile_cols);
+size_t asx_plan_group(const asx_plan *plan);          /* pairs per launch group */
+size_t asx_plan_workspace_bytes(const asx_plan *plan);
+
+/* ---- the hot path ------------------------------------------------------ */
+
+/* One pair, host double buffers: the reference's own calling convention.
+ * source: 2N doubles (read only), sample: N doubles.  Copies to the device,
+ * converts to float32 there, runs the transforms in float32 and the Pearson
+ * reduction in float64 on the ORIGINAL doubles.  Returns 0, or -1 exactly
+ * where the reference does (device/allocation failure: outputs untouched;
+ * NaN coefficient: outputs written). */
+int asx_xcorr_f64(asx_plan *plan, const double *source, const double *sample, long *lag,
+                  double *coefficient);
+
+/* `batch` pairs, host float32 buffers laid out pair after pair:
+ * source[batch][2N], sample[batch][N].  lag/coef/ret: `batch` entries each. */
+int asx_xcorr_batch_f32(asx_plan *plan, const float *source, const float *sample, size_t batch,
+                        int64_t *lag, double *coef, int32_t *ret);
+
+/* Same with everything already resident in this plan's device memory space.
+ * All pointers are DEVICE pointers; `stream` is a hipStream_t (NULL = the
+ * plan's own stream).  Asynchronous: results are valid after the stream is
+ * synchronised.  source pairs are 2N floats apart, sample pairs N floats. */
+int asx_xcorr_batch_f32_dev(asx_plan *plan, const float *d_source, const float *d_sample,
+                            size_t batch, int64_t *d_lag, double *d_coef, int32_t *d_ret,
+                            void *stream);
+
+/* Debug/parity aid: run ONE device-resident pair and also return the raw
+ * correlation r[0..2N) (device pointer, 2N floats; scaled by F/(2N) relative
+ * to the reference when the length had to be embedded). */
+int asx_xcorr_debug_r_dev(asx_plan *plan, const float *d_source, const float *d_sample,
+                          float *d_r, int64_t *d_lag, double *d_coef, int32_t *d_ret,
+                          void *stream);
+
+/* pearson_coefficient() on two equal-length host double ranges. Writes the
+ * coefficient (NaN for a constant range, like the reference). */
+int asx_pearson_f64(const double *source_seg, const double *sample_seg, size_t n, int device,
+                    double *coefficient);
+
+/* ---- synthetic inputs and timing -------------------------------------- */
+
+/* Fill device buffers with pairs [first_pair, first_pair+count) of the
+ * deterministic generator specified in oracle/xcorr_oracle.h (bit-identical
+ * to oracle_synth_pair).  d_true_lag may be NULL. */
+int asx_synth_pairs_dev(uint64_t seed, uint64_t first_pair, size_t count, size_t sample_len,
+                        int noise_shift, float *d_source, float *d_sample, int64_t *d_true_lag,
+                        void *stream);
+
+/* Milliseconds spent by the most recent asx_xcorr_batch_f32_dev call on
+ * `plan`, per kernel family, measured with HIP events on the stream the
+ * kernels ran on.  Only filled when profiling was enabled before the call.
+ * out[0..5] = fwd_cols, rows, inv_cols, finalize, pearson, total. */
+int asx_plan_set_profiling(asx_plan *plan, int enabled);
+int asx_plan_last_timings_ms(asx_plan *plan, float out[6]);
+
+/* Raw device memory helpers so a C host (no torch) can stage buffers. */
+void *asx_device_malloc(size_t bytes, int device);
+int asx_device_free(void *ptr);
+int asx_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes);
+int asx_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes);
+int asx_stream_sync(asx_plan *plan, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,536 @@
+// csrc/asx_api.hip — host side of the HIP layer: plans, workspaces, the C-ABI
+// declared in include/audiosync/xcorr_hip.h.  No CPU fallback anywhere: when
+// HIP is not usable every entry point fails and says so.
+#include "audiosync/xcorr_hip.h"
+
+#include "asx_internal.h"
+#include "plan_math.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+// ---------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------
+static thread_local std::string g_err;
+
+static int fail(const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    // same channel and prefix as the reference's perror("audiosync: ...") calls
+    fprintf(stderr, "audiosync: %s\n", buf);
+    return -1;
+}
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+#define HIP_TRY_NULL(expr)                                                                    \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__);  \
+            return nullptr;                                                                   \
+        }                                                                                     \
+    } while (0)
+
+extern "C" const char *asx_last_error(void) { return g_err.c_str(); }
+extern "C" int asx_abi_version(void) { return 1; }
+
+extern "C" int asx_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+// ---------------------------------------------------------------------------
+// plan
+// ---------------------------------------------------------------------------
+struct asx_plan {
+    int device = 0;
+    AsxHostPlan host;
+    AsxDev dev{};
+    size_t group = 1;          // pairs per launch group
+    size_t ws_bytes = 0;
+    hipStream_t stream = nullptr;
+    std::mutex lock;
+
+    // device tables
+    std::vector<void *> allocs; // everything to hipFree on destroy
+    // workspaces for one group
+    float2 *zxa = nullptr, *zya = nullptr, *ga = nullptr;
+    asx_peak_t *partials = nullptr;
+    AsxSeg *seg = nullptr;
+    double *psums = nullptr;
+    // staging for the host-pointer entry points (lazy)
+    float *st_src = nullptr, *st_smp = nullptr;
+    int64_t *st_lag = nullptr;
+    double *st_coef = nullptr;
+    int32_t *st_ret = nullptr;
+    double *st_src64 = nullptr, *st_smp64 = nullptr;
+
+    bool profiling = false;
+    std::vector<hipEvent_t> ev;      // 6 per group of the last call
+    size_t ev_groups = 0;
+};
+
+template <typename T> static int dev_alloc(asx_plan *p, T **out, size_t count)
+{
+    void *ptr = nullptr;
+    size_t bytes = count * sizeof(T);
+    if (bytes == 0) bytes = sizeof(T);
+    HIP_TRY(hipMalloc(&ptr, bytes));
+    p->allocs.push_back(ptr);
+    p->ws_bytes += bytes;
+    *out = static_cast<T *>(ptr);
+    return 0;
+}
+
+template <typename T> static int dev_upload(asx_plan *p, const T **out, const std::vector<T> &v)
+{
+    T *d = nullptr;
+    if (dev_alloc(p, &d, v.size()) != 0) return -1;
+    HIP_TRY(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    *out = d;
+    return 0;
+}
+
+static int plan_init(asx_plan *p, size_t N, size_t max_batch, const char *split)
+{
+    if (!split || !*split) split = getenv("ASX_SPLIT");
+    std::string err = asx_host_plan_build(N, split, &p->host);
+    if (!err.empty()) return fail("plan for sample_len=%zu: %s", N, err.c_str());
+    const AsxHostPlan &h = p->host;
+    AsxDev &d = p->dev;
+    d.N = (uint32_t)N;
+    d.F = h.F; d.M = h.M; d.M1 = h.M1; d.M2 = h.M2; d.T = h.T; d.logT = h.logT; d.ntiles = h.ntiles;
+    d.src_valid = h.src_valid;
+    d.src_period = (uint32_t)(2 * N);
+    d.nout = (uint32_t)(2 * N);
+    d.st1 = h.st1; d.st2 = h.st2;
+    if (dev_upload(p, &d.tw1, h.tw1) || dev_upload(p, &d.tw2, h.tw2) || dev_upload(p, &d.tw_lo, h.tw_lo) ||
+        dev_upload(p, &d.tw_hi, h.tw_hi) || dev_upload(p, &d.tw_b, h.tw_b) ||
+        dev_upload(p, &d.k1_of_pos1, h.k1_of_pos1) || dev_upload(p, &d.pos1_of_k1, h.pos1_of_k1) ||
+        dev_upload(p, &d.pos2_of_k2, h.pos2_of_k2))
+        return -1;
+
+    // group size: keep the three inter-kernel intermediates (24*M bytes per pair) of one
+    // group around the size of the 256 MiB Infinity Cache so the next kernel re-reads them on die
+    size_t ws_mb = 160;
+    if (const char *e = getenv("ASX_WS_MB")) ws_mb = (size_t)atol(e) > 0 ? (size_t)atol(e) : ws_mb;
+    size_t per_pair = (size_t)3 * h.M * sizeof(float2);
+    size_t g = (ws_mb << 20) / per_pair;
+    if (g < 1) g = 1;
+    if (g > 65535) g = 65535; // grid.y / grid.z limit
+    if (max_batch < 1) max_batch = 1;
+    if (g > max_batch) g = max_batch;
+    p->group = g;
+    if (dev_alloc(p, &p->zxa, g * h.M) || dev_alloc(p, &p->zya, g * h.M) || dev_alloc(p, &p->ga, g * h.M) ||
+        dev_alloc(p, &p->partials, g * (size_t)h.ntiles) || dev_alloc(p, &p->seg, g) ||
+        dev_alloc(p, &p->psums, g * ASX_PEARSON_BLOCKS * 5))
+        return -1;
+    HIP_TRY(hipStreamCreate(&p->stream));
+    return 0;
+}
+
+extern "C" asx_plan *asx_plan_create_ex(size_t sample_len, size_t max_batch, int device, const char *split)
+{
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0) {
+        fail("no usable HIP device (%s); this library has no CPU fallback",
+             e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+        return nullptr;
+    }
+    if (device < 0) HIP_TRY_NULL(hipGetDevice(&device));
+    if (device >= ndev) {
+        fail("device %d out of range (%d devices)", device, ndev);
+        return nullptr;
+    }
+    int prev = 0;
+    HIP_TRY_NULL(hipGetDevice(&prev));
+    HIP_TRY_NULL(hipSetDevice(device));
+    asx_plan *p = new asx_plan();
+    p->device = device;
+    int rc = plan_init(p, sample_len, max_batch, split);
+    (void)hipSetDevice(prev);
+    if (rc != 0) {
+        asx_plan_destroy(p);
+        return nullptr;
+    }
+    return p;
+}
+
+extern "C" asx_plan *asx_plan_create(size_t sample_len, size_t max_batch, int device)
+{
+    return asx_plan_create_ex(sample_len, max_batch, device, nullptr);
+}
+
+extern "C" void asx_plan_destroy(asx_plan *p)
+{
+    if (!p) return;
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    (void)hipSetDevice(p->device);
+    if (p->stream) { (void)hipStreamSynchronize(p->stream); (void)hipStreamDestroy(p->stream); }
+    for (hipEvent_t ev : p->ev) (void)hipEventDestroy(ev);
+    for (void *a : p->allocs) (void)hipFree(a);
+    (void)hipSetDevice(prev);
+    delete p;
+}
+
+extern "C" size_t asx_plan_sample_len(const asx_plan *p) { return p ? p->host.N : 0; }
+extern "C" size_t asx_plan_fft_len(const asx_plan *p) { return p ? p->host.F : 0; }
+extern "C" size_t asx_plan_group(const asx_plan *p) { return p ? p->group : 0; }
+extern "C" size_t asx_plan_workspace_bytes(const asx_plan *p) { return p ? p->ws_bytes : 0; }
+extern "C" int asx_plan_split(const asx_plan *p, int *m1, int *m2, int *tile_cols)
+{
+    if (!p) return -1;
+    if (m1) *m1 = p->host.M1;
+    if (m2) *m2 = p->host.M2;
+    if (tile_cols) *tile_cols = p->host.T;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// running groups
+// ---------------------------------------------------------------------------
+struct DevGuard {
+    int prev = -1;
+    bool ok = false;
+    explicit DevGuard(int dev)
+    {
+        if (hipGetDevice(&prev) == hipSuccess && hipSetDevice(dev) == hipSuccess) ok = true;
+    }
+    ~DevGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+static int prof_mark(asx_plan *p, hipStream_t s, size_t slot)
+{
+    if (!p->profiling) return 0;
+    while (p->ev.size() <= slot) {
+        hipEvent_t ev;
+        HIP_TRY(hipEventCreate(&ev));
+        p->ev.push_back(ev);
+    }
+    HIP_TRY(hipEventRecord(p->ev[slot], s));
+    return 0;
+}
+
+// one group: g <= plan->group pairs, inputs device resident.  TIn selects the Pearson input type.
+template <typename TIn>
+static int run_group(asx_plan *p, const float *d_src, const float *d_smp, const TIn *p_src,
+                     const TIn *p_smp, size_t g, int64_t *d_lag, double *d_coef, int32_t *d_ret,
+                     float *d_r, hipStream_t s, size_t group_index)
+{
+    const AsxDev &P = p->dev;
+    const size_t e0 = group_index * 6;
+    if (prof_mark(p, s, e0 + 0)) return -1;
+    asx_launch_fwd_cols(P, d_src, d_smp, p->zxa, p->zya, (int)g, s);
+    if (prof_mark(p, s, e0 + 1)) return -1;
+    asx_launch_rows(P, p->zxa, p->zya, p->ga, (int)g, s);
+    if (prof_mark(p, s, e0 + 2)) return -1;
+    asx_launch_inv_cols(P, p->ga, p->partials, d_r, (int)g, s);
+    if (prof_mark(p, s, e0 + 3)) return -1;
+    asx_launch_finalize(P, p->partials, p->seg, (int)g, s);
+    if (prof_mark(p, s, e0 + 4)) return -1;
+    if (sizeof(TIn) == sizeof(float))
+        asx_launch_pearson_f32((const float *)p_src, (const float *)p_smp, 2 * (size_t)P.N, P.N, P.N,
+                               p->seg, p->psums, d_lag, d_coef, d_ret, (int)g, s);
+    else
+        asx_launch_pearson_f64((const double *)p_src, (const double *)p_smp, 2 * (size_t)P.N, P.N, P.N,
+                               p->seg, p->psums, d_lag, d_coef, d_ret, (int)g, s);
+    if (prof_mark(p, s, e0 + 5)) return -1;
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int asx_xcorr_batch_f32_dev(asx_plan *p, const float *d_source, const float *d_sample,
+                                       size_t batch, int64_t *d_lag, double *d_coef, int32_t *d_ret,
+                                       void *stream)
+{
+    if (!p || !d_source || !d_sample || !d_coef) return fail("asx_xcorr_batch_f32_dev: null argument");
+    std::lock_guard<std::mutex> guard(p->lock);
+    DevGuard dg(p->device);
+    if (!dg.ok) return fail("cannot select device %d", p->device);
+    hipStream_t s = stream ? (hipStream_t)stream : p->stream;
+    const size_t N = p->host.N;
+    p->ev_groups = 0;
+    size_t gi = 0;
+    for (size_t done = 0; done < batch; done += p->group, gi++) {
+        const size_t g = std::min(p->group, batch - done);
+        if (run_group<float>(p, d_source + done * 2 * N, d_sample + done * N, d_source + done * 2 * N,
+                             d_sample + done * N, g, d_lag ? d_lag + done : nullptr, d_coef + done,
+                             d_ret ? d_ret + done : nullptr, nullptr, s, gi))
+            return -1;
+    }
+    p->ev_groups = p->profiling ? gi : 0;
+    return 0;
+}
+
+extern "C" int asx_xcorr_debug_r_dev(asx_plan *p, const float *d_source, const float *d_sample,
+                                     float *d_r, int64_t *d_lag, double *d_coef, int32_t *d_ret,
+                                     void *stream)
+{
+    if (!p || !d_source || !d_sample || !d_coef || !d_r) return fail("asx_xcorr_debug_r_dev: null argument");
+    std::lock_guard<std::mutex> guard(p->lock);
+    DevGuard dg(p->device);
+    if (!dg.ok) return fail("cannot select device %d", p->device);
+    hipStream_t s = stream ? (hipStream_t)stream : p->stream;
+    p->ev_groups = 0;
+    return run_group<float>(p, d_source, d_sample, d_source, d_sample, 1, d_lag, d_coef, d_ret, d_r, s, 0);
+}
+
+static int ensure_staging(asx_plan *p)
+{
+    if (p->st_src) return 0;
+    const size_t N = p->host.N, g = p->group;
+    if (dev_alloc(p, &p->st_src, g * 2 * N) || dev_alloc(p, &p->st_smp, g * N) ||
+        dev_alloc(p, &p->st_lag, g) || dev_alloc(p, &p->st_coef, g) || dev_alloc(p, &p->st_ret, g))
+        return -1;
+    return 0;
+}
+
+extern "C" int asx_xcorr_batch_f32(asx_plan *p, const float *source, const float *sample, size_t batch,
+                                   int64_t *lag, double *coef, int32_t *ret)
+{
+    if (!p || !source || !sample || !lag || !coef || !ret) return fail("asx_xcorr_batch_f32: null argument");
+    std::lock_guard<std::mutex> guard(p->lock);
+    DevGuard dg(p->device);
+    if (!dg.ok) return fail("cannot select device %d", p->device);
+    if (ensure_staging(p)) return -1;
+    const size_t N = p->host.N;
+    hipStream_t s = p->stream;
+    p->ev_groups = 0;
+    for (size_t done = 0; done < batch; done += p->group) {
+        const size_t g = std::min(p->group, batch - done);
+        HIP_TRY(hipMemcpyAsync(p->st_src, source + done * 2 * N, g * 2 * N * sizeof(float), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(p->st_smp, sample + done * N, g * N * sizeof(float), hipMemcpyHostToDevice, s));
+        if (run_group<float>(p, p->st_src, p->st_smp, p->st_src, p->st_smp, g, p->st_lag, p->st_coef,
+                             p->st_ret, nullptr, s, 0))
+            return -1;
+        HIP_TRY(hipMemcpyAsync(lag + done, p->st_lag, g * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(coef + done, p->st_coef, g * sizeof(double), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(ret + done, p->st_ret, g * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    return 0;
+}
+
+extern "C" int asx_xcorr_f64(asx_plan *p, const double *source, const double *sample, long *lag,
+                             double *coefficient)
+{
+    if (!p || !source || !sample || !lag || !coefficient) return fail("asx_xcorr_f64: null argument");
+    std::lock_guard<std::mutex> guard(p->lock);
+    DevGuard dg(p->device);
+    if (!dg.ok) return fail("cannot select device %d", p->device);
+    if (ensure_staging(p)) return -1;
+    const size_t N = p->host.N;
+    if (!p->st_src64) {
+        if (dev_alloc(p, &p->st_src64, 2 * N) || dev_alloc(p, &p->st_smp64, N)) return -1;
+    }
+    hipStream_t s = p->stream;
+    p->ev_groups = 0;
+    HIP_TRY(hipMemcpyAsync(p->st_src64, source, 2 * N * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(p->st_smp64, sample, N * sizeof(double), hipMemcpyHostToDevice, s));
+    asx_launch_cvt_f64_f32(p->st_src64, p->st_src, 2 * N, s);
+    asx_launch_cvt_f64_f32(p->st_smp64, p->st_smp, N, s);
+    if (run_group<double>(p, p->st_src, p->st_smp, p->st_src64, p->st_smp64, 1, p->st_lag, p->st_coef,
+                          p->st_ret, nullptr, s, 0))
+        return -1;
+    int64_t h_lag = 0;
+    double h_coef = 0;
+    int32_t h_ret = -1;
+    HIP_TRY(hipMemcpyAsync(&h_lag, p->st_lag, sizeof(h_lag), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(&h_coef, p->st_coef, sizeof(h_coef), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(&h_ret, p->st_ret, sizeof(h_ret), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    *lag = (long)h_lag;
+    *coefficient = h_coef;
+    return h_ret;
+}
+
+extern "C" int asx_pearson_f64(const double *a, const double *b, size_t n, int device, double *out)
+{
+    if (!a || !b || !out) return fail("asx_pearson_f64: null argument");
+    if (n > 0xFFFFFFFFull) return fail("asx_pearson_f64: range too long");
+    if (asx_device_count() == 0) return fail("no usable HIP device; this library has no CPU fallback");
+    if (device < 0) HIP_TRY(hipGetDevice(&device));
+    DevGuard dg(device);
+    if (!dg.ok) return fail("cannot select device %d", device);
+    double *d_a = nullptr, *d_b = nullptr, *d_ps = nullptr, *d_c = nullptr;
+    AsxSeg *d_seg = nullptr;
+    int rc = -1;
+    AsxSeg seg{};
+    seg.lag = 0; seg.src_off = 0; seg.smp_off = 0; seg.len = (uint32_t)n; seg.peak = 0;
+    do {
+        if (hipMalloc((void **)&d_a, (n ? n : 1) * sizeof(double)) != hipSuccess) break;
+        if (hipMalloc((void **)&d_b, (n ? n : 1) * sizeof(double)) != hipSuccess) break;
+        if (hipMalloc((void **)&d_ps, ASX_PEARSON_BLOCKS * 5 * sizeof(double)) != hipSuccess) break;
+        if (hipMalloc((void **)&d_c, sizeof(double)) != hipSuccess) break;
+        if (hipMalloc((void **)&d_seg, sizeof(AsxSeg)) != hipSuccess) break;
+        if (hipMemcpy(d_a, a, n * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) break;
+        if (hipMemcpy(d_b, b, n * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) break;
+        if (hipMemcpy(d_seg, &seg, sizeof(seg), hipMemcpyHostToDevice) != hipSuccess) break;
+        asx_launch_pearson_f64(d_a, d_b, 0, 0, (uint32_t)n, d_seg, d_ps, nullptr, d_c, nullptr, 1, nullptr);
+        if (hipGetLastError() != hipSuccess) break;
+        if (hipMemcpy(out, d_c, sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) break;
+        rc = 0;
+    } while (0);
+    if (rc != 0) fail("asx_pearson_f64: HIP failure: %s", hipGetErrorString(hipGetLastError()));
+    (void)hipFree(d_a); (void)hipFree(d_b); (void)hipFree(d_ps); (void)hipFree(d_c); (void)hipFree(d_seg);
+    return rc;
+}
+
+// ---------------------------------------------------------------------------
+// synthetic inputs, timing, raw memory helpers
+// ---------------------------------------------------------------------------
+extern "C" int asx_synth_pairs_dev(uint64_t seed, uint64_t first_pair, size_t count, size_t sample_len,
+                                   int noise_shift, float *d_source, float *d_sample,
+                                   int64_t *d_true_lag, void *stream)
+{
+    if (!d_source || !d_sample) return fail("asx_synth_pairs_dev: null argument");
+    if (sample_len == 0 || sample_len > (1u << 30)) return fail("asx_synth_pairs_dev: bad sample_len");
+    for (size_t done = 0; done < count; done += 32768) {
+        const size_t c = std::min((size_t)32768, count - done);
+        asx_launch_synth(seed, first_pair + done, c, (uint32_t)sample_len, noise_shift,
+                         d_source + done * 2 * sample_len, d_sample + done * sample_len,
+                         d_true_lag ? d_true_lag + done : nullptr, (hipStream_t)stream);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int asx_plan_set_profiling(asx_plan *p, int enabled)
+{
+    if (!p) return -1;
+    std::lock_guard<std::mutex> guard(p->lock);
+    p->profiling = enabled != 0;
+    p->ev_groups = 0;
+    return 0;
+}
+
+extern "C" int asx_plan_last_timings_ms(asx_plan *p, float out[6])
+{
+    if (!p || !out) return -1;
+    std::lock_guard<std::mutex> guard(p->lock);
+    for (int i = 0; i < 6; i++) out[i] = 0.f;
+    if (p->ev_groups == 0) return fail("no profiled call recorded");
+    DevGuard dg(p->device);
+    for (size_t g = 0; g < p->ev_groups; g++) {
+        HIP_TRY(hipEventSynchronize(p->ev[g * 6 + 5]));
+        for (int k = 0; k < 5; k++) {
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, p->ev[g * 6 + k], p->ev[g * 6 + k + 1]));
+            out[k] += ms;
+        }
+    }
+    float total = 0.f;
+    HIP_TRY(hipEventElapsedTime(&total, p->ev[0], p->ev[(p->ev_groups - 1) * 6 + 5]));
+    out[5] = total;
+    return 0;
+}
+
+extern "C" void *asx_device_malloc(size_t bytes, int device)
+{
+    int prev = 0;
+    if (device >= 0) {
+        HIP_TRY_NULL(hipGetDevice(&prev));
+        HIP_TRY_NULL(hipSetDevice(device));
+    }
+    void *ptr = nullptr;
+    hipError_t e = hipMalloc(&ptr, bytes ? bytes : 1);
+    if (device >= 0) (void)hipSetDevice(prev);
+    if (e != hipSuccess) {
+        fail("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        return nullptr;
+    }
+    return ptr;
+}
+
+extern "C" int asx_device_free(void *ptr)
+{
+    HIP_TRY(hipFree(ptr));
+    return 0;
+}
+
+extern "C" int asx_memcpy_h2d(void *dst, const void *src, size_t bytes)
+{
+    HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return 0;
+}
+
+extern "C" int asx_memcpy_d2h(void *dst, const void *src, size_t bytes)
+{
+    HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int asx_stream_sync(asx_plan *p, void *stream)
+{
+    hipStream_t s = stream ? (hipStream_t)stream : (p ? p->stream : nullptr);
+    if (p) {
+        DevGuard dg(p->device);
+        HIP_TRY(hipStreamSynchronize(s));
+        return 0;
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// planning arithmetic exposed for the CPU test-suite (no HIP calls)
+// ---------------------------------------------------------------------------
+extern "C" int asx_planmath_describe(size_t sample_len, const char *split, uint32_t *F, uint32_t *src_valid,
+                                     int *M1, int *M2, int *T, int *nst1, int *radix1, int *nst2,
+                                     int *radix2)
+{
+    AsxHostPlan h;
+    std::string err = asx_host_plan_build(sample_len, split, &h);
+    if (!err.empty()) return fail("%s", err.c_str());
+    *F = h.F; *src_valid = h.src_valid; *M1 = h.M1; *M2 = h.M2; *T = h.T;
+    *nst1 = h.st1.nstages; *nst2 = h.st2.nstages;
+    for (int i = 0; i < h.st1.nstages; i++) radix1[i] = h.st1.radix[i];
+    for (int i = 0; i < h.st2.nstages; i++) radix2[i] = h.st2.radix[i];
+    return 0;
+}
+
+// tables: which = 0 pos1_of_k1 (M1 ints), 1 k1_of_pos1 (M1), 2 pos2_of_k2 (M2)
+extern "C" int asx_planmath_table(size_t sample_len, const char *split, int which, int *out, size_t cap)
+{
+    AsxHostPlan h;
+    std::string err = asx_host_plan_build(sample_len, split, &h);
+    if (!err.empty()) return fail("%s", err.c_str());
+    const std::vector<int> &t = which == 0 ? h.pos1_of_k1 : which == 1 ? h.k1_of_pos1 : h.pos2_of_k2;
+    if (t.size() > cap) return fail("table larger than buffer");
+    memcpy(out, t.data(), t.size() * sizeof(int));
+    return (int)t.size();
+}
+
+// twiddle tables: which = 0 tw1, 1 tw2, 2 tw_lo, 3 tw_hi, 4 tw_b ; out = interleaved re,im floats
+extern "C" int asx_planmath_twiddles(size_t sample_len, const char *split, int which, float *out, size_t cap)
+{
+    AsxHostPlan h;
+    std::string err = asx_host_plan_build(sample_len, split, &h);
+    if (!err.empty()) return fail("%s", err.c_str());
+    const std::vector<float2> &t =
+        which == 0 ? h.tw1 : which == 1 ? h.tw2 : which == 2 ? h.tw_lo : which == 3 ? h.tw_hi : h.tw_b;
+    if (t.size() > cap) return fail("table larger than buffer");
+    memcpy(out, t.data(), t.size() * sizeof(float2));
+    return (int)t.size();
+}

@@ -1,0 +1,89 @@
+// csrc/asx_internal.h — shared between the host side of the HIP layer
+// (asx_api.hip) and the gfx950 kernels (xcorr_kernels.hip).
+//
+// Notation (also used in DESIGN.md and tests/model_fourstep.py):
+//   N   sample_len                      F   real transform length (even)
+//   M   F/2, complex transform length   M = M1*M2
+//   j = j1*M2 + j2  (time index of the packed complex sequence)
+//   k = k1 + M1*k2  (frequency index)
+//   every intermediate in HBM is row-major [M1][M2] per pair
+//   rows of the spectra sit at the DIGIT-REVERSED position pos1[k1]
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define ASX_MAX_STAGES 12
+#define ASX_TW_LOG 11                       // two-level twiddle: low table has 2^11 entries
+#define ASX_TW_LO (1u << ASX_TW_LOG)
+#define ASX_THREADS 256                     // block size of every kernel here
+#define ASX_PEARSON_BLOCKS 64               // partial-sum blocks per pair
+
+// Radix schedule of one in-LDS transform of length n.
+// DIF stage i works on sub-blocks of length ns[i] = n / (radix[0]*...*radix[i-1]).
+struct AsxStages {
+    int n;
+    int nstages;
+    int radix[ASX_MAX_STAGES];
+    int ns[ASX_MAX_STAGES];                 // sub-block length at DIF stage i
+    int q[ASX_MAX_STAGES];                  // ns / radix  (butterflies per sub-block, and the leg stride)
+    int nbf[ASX_MAX_STAGES];                // n / radix   (butterflies per transform)
+    int twmul[ASX_MAX_STAGES];              // n / ns      (step in the w_n table for this stage)
+    float inv_q[ASX_MAX_STAGES];            // 1/q and 1/nbf for the exact float division helper
+    float inv_nbf[ASX_MAX_STAGES];
+};
+
+// Everything a kernel needs to know about a plan; passed by value.
+struct AsxDev {
+    uint32_t N;            // sample_len
+    uint32_t F, M;         // real / complex transform length
+    int M1, M2;            // M = M1*M2
+    int T, logT;           // tile width (columns per block) of the column kernels, power of two
+    int ntiles;            // ceil(M2 / T)
+    uint32_t src_valid;    // how many leading real samples of the (periodically extended) source are non-zero
+    uint32_t src_period;   // 2N
+    uint32_t nout;         // 2N: lags searched
+    AsxStages st1, st2;    // schedules for length M1 and M2
+    const float2 *tw1;     // w_{M1}^q, q < M1
+    const float2 *tw2;     // w_{M2}^q, q < M2
+    const float2 *tw_lo;   // w_F^q, q < 2^ASX_TW_LOG
+    const float2 *tw_hi;   // w_F^(h * 2^ASX_TW_LOG)
+    const float2 *tw_b;    // w_F^(M1*k2), k2 < M2
+    const int *k1_of_pos1; // row slot -> k1
+    const int *pos1_of_k1; // k1 -> row slot
+    const int *pos2_of_k2; // k2 -> slot inside a row after the forward row transform
+};
+
+// Peak-search partial: order-preserving key in the high word, ~index in the low word,
+// so that a plain unsigned max picks the largest key and, among equals, the smallest index
+// (src/cross_correlation.c:60 uses a strict '>').
+typedef unsigned long long asx_peak_t;
+
+struct AsxSeg {           // per pair, produced by k_finalize
+    long long lag;        // wrapped lag (src/cross_correlation.c:256-271)
+    uint32_t src_off;     // first source frame of the compared segment
+    uint32_t smp_off;     // first sample frame
+    uint32_t len;         // segment length (N, or N-|lag|; may be 0)
+    uint32_t peak;        // raw argmax index in [0, 2N)
+};
+
+// kernel launchers (defined in xcorr_kernels.hip, called from asx_api.hip)
+void asx_launch_fwd_cols(const AsxDev &P, const float *src, const float *smp, float2 *zxa,
+                         float2 *zya, int npairs, hipStream_t s);
+void asx_launch_rows(const AsxDev &P, const float2 *zxa, const float2 *zya, float2 *ga, int npairs,
+                     hipStream_t s);
+void asx_launch_inv_cols(const AsxDev &P, const float2 *ga, asx_peak_t *partials, float *r_out,
+                         int npairs, hipStream_t s);
+void asx_launch_finalize(const AsxDev &P, const asx_peak_t *partials, AsxSeg *seg, int npairs,
+                         hipStream_t s);
+void asx_launch_pearson_f32(const float *src, const float *smp, size_t src_pitch, size_t smp_pitch,
+                            uint32_t basis_len, const AsxSeg *seg, double *psums, int64_t *lag,
+                            double *coef, int32_t *ret, int npairs, hipStream_t s);
+void asx_launch_pearson_f64(const double *src, const double *smp, size_t src_pitch, size_t smp_pitch,
+                            uint32_t basis_len, const AsxSeg *seg, double *psums, int64_t *lag,
+                            double *coef, int32_t *ret, int npairs, hipStream_t s);
+void asx_launch_cvt_f64_f32(const double *in, float *out, size_t n, hipStream_t s);
+void asx_launch_synth(uint64_t seed, uint64_t first_pair, size_t count, uint32_t N,
+                      int noise_shift, float *src, float *smp, int64_t *true_lag, hipStream_t s);
+size_t asx_lds_bytes_cols(const AsxDev &P);
+size_t asx_lds_bytes_rows(const AsxDev &P);

@@ -1,0 +1,171 @@
+// csrc/plan_math.cpp — see plan_math.h.  Pure host arithmetic.
+#include "plan_math.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+
+bool asx_is_smooth(uint64_t n)
+{
+    if (n == 0) return false;
+    for (uint64_t p : { 2ull, 3ull, 5ull })
+        while (n % p == 0) n /= p;
+    return n == 1;
+}
+
+uint64_t asx_next_smooth_even(uint64_t n)
+{
+    n += n & 1ull;
+    if (n < 2) n = 2;
+    while (!asx_is_smooth(n)) n += 2;
+    return n;
+}
+
+bool asx_make_stages(int n, AsxStages *st)
+{
+    *st = AsxStages{};
+    st->n = n;
+    int rem = n, ns = n, i = 0;
+    auto push = [&](int R) {
+        st->radix[i] = R;
+        st->ns[i] = ns;
+        st->q[i] = ns / R;
+        st->nbf[i] = n / R;
+        st->twmul[i] = n / ns;
+        st->inv_q[i] = 1.0f / (float)(ns / R);
+        st->inv_nbf[i] = 1.0f / (float)(n / R);
+        ns /= R;
+        rem /= R;
+        i++;
+    };
+    for (int R : { 4, 2, 3, 5 }) {
+        while (rem % R == 0) {
+            if (i >= ASX_MAX_STAGES) return false;
+            push(R);
+        }
+    }
+    st->nstages = i;
+    return rem == 1;
+}
+
+std::vector<int> asx_position_table(const AsxStages &st)
+{
+    // k = u0 + R0*u1 + R0*R1*u2 + ...  ->  pos = u0*(n/R0) + u1*(n/(R0*R1)) + ...
+    std::vector<int> pos(st.n);
+    for (int k = 0; k < st.n; k++) {
+        int rem = k, p = 0, stride = st.n;
+        for (int i = 0; i < st.nstages; i++) {
+            stride /= st.radix[i];
+            p += (rem % st.radix[i]) * stride;
+            rem /= st.radix[i];
+        }
+        pos[k] = p;
+    }
+    return pos;
+}
+
+static float2 unit_root(uint64_t num, uint64_t den)
+{
+    // exp(-2*pi*i*num/den) evaluated in double, rounded once to float
+    num %= den;
+    const double x = (double)num / (double)den;
+    float2 w;
+    if (num == 0) return make_float2(1.f, 0.f);
+    if (4 * num == den) return make_float2(0.f, -1.f);
+    if (2 * num == den) return make_float2(-1.f, 0.f);
+    if (4 * num == 3 * den) return make_float2(0.f, 1.f);
+    const double a = 2.0 * M_PI * x;
+    w.x = (float)cos(a);
+    w.y = (float)(-sin(a));
+    return w;
+}
+
+static int pow2_floor(size_t v)
+{
+    int p = 1;
+    while ((size_t)p * 2 <= v) p *= 2;
+    return p;
+}
+
+static int tile_for(int M1)
+{
+    size_t cap = ASX_LDS_COLS_MAX / sizeof(float2) / (size_t)M1;
+    if (cap < 1) return 0;
+    int T = pow2_floor(cap);
+    if (T > 64) T = 64;
+    return T;
+}
+
+std::string asx_host_plan_build(size_t N, const char *split_override, AsxHostPlan *hp)
+{
+    if (N == 0) return "sample_len must be > 0";
+    if (N > (size_t)1 << 27) return "sample_len too large";
+    hp->N = N;
+    uint64_t F = 2 * (uint64_t)N, valid = 2 * (uint64_t)N;
+    if (!asx_is_smooth(F)) {
+        // embed: r[k] = sum_n s'[n+k] sample[n] with s' the source extended periodically to
+        // 3N-1 samples; any smooth even F >= 3N-1 gives the same r[0..2N) without wrap-around.
+        valid = 3 * (uint64_t)N - 1;
+        F = asx_next_smooth_even(valid);
+    }
+    if (F >= (1ull << 31)) return "transform length too large";
+    hp->F = (uint32_t)F;
+    hp->M = (uint32_t)(F / 2);
+    hp->src_valid = (uint32_t)valid;
+    const uint32_t M = hp->M;
+    const int rows_max = (int)(ASX_LDS_ROWS_MAX / (4 * sizeof(float2)));
+
+    int M1 = 0, M2 = 0, T = 0;
+    if (split_override && *split_override) {
+        if (sscanf(split_override, "%dx%dx%d", &M1, &M2, &T) != 3 || M1 < 1 || M2 < 1 ||
+            (uint64_t)M1 * (uint64_t)M2 != M || T < 1 || (T & (T - 1)) || T > 64 ||
+            (size_t)M1 * T * sizeof(float2) > ASX_LDS_HW_MAX ||
+            (size_t)4 * M2 * sizeof(float2) > ASX_LDS_HW_MAX)
+            return "bad ASX_SPLIT override";
+    } else {
+        // smallest worst-case LDS footprint, preferring tiles of at least 8 columns
+        // (64-byte row segments) and then wider tiles
+        size_t best_cost = (size_t)-1;
+        for (int pass = 0; pass < 2 && M1 == 0; pass++) {
+            const int min_T = pass == 0 ? 8 : 1;
+            for (uint32_t a = 1; a <= M && a <= 8192u; a++) {
+                if (M % a) continue;
+                const uint32_t b = M / a;
+                if ((int)b > rows_max) continue;
+                int t = tile_for((int)a);
+                if (t < min_T) continue;
+                while (t > 1 && (uint32_t)t > b) t >>= 1; // never wider than the row
+                size_t cost = std::max((size_t)a * t * sizeof(float2), (size_t)4 * b * sizeof(float2));
+                if (cost < best_cost || (cost == best_cost && t > T)) {
+                    best_cost = cost;
+                    M1 = (int)a; M2 = (int)b; T = t;
+                }
+            }
+        }
+        if (M1 == 0) return "transform length does not split into LDS-sized factors";
+    }
+    hp->M1 = M1; hp->M2 = M2; hp->T = T;
+    hp->logT = 0;
+    while ((1 << hp->logT) < T) hp->logT++;
+    hp->ntiles = (M2 + T - 1) / T;
+    if (!asx_make_stages(M1, &hp->st1) || !asx_make_stages(M2, &hp->st2))
+        return "factor is not {2,3,5}-smooth";
+
+    hp->tw1.resize(M1);
+    for (int q = 0; q < M1; q++) hp->tw1[q] = unit_root(q, M1);
+    hp->tw2.resize(M2);
+    for (int q = 0; q < M2; q++) hp->tw2[q] = unit_root(q, M2);
+    hp->tw_lo.resize(ASX_TW_LO);
+    for (uint32_t q = 0; q < ASX_TW_LO; q++) hp->tw_lo[q] = unit_root(q, F);
+    const uint32_t nhi = (uint32_t)((F + ASX_TW_LO - 1) >> ASX_TW_LOG) + 1;
+    hp->tw_hi.resize(nhi);
+    for (uint32_t h = 0; h < nhi; h++) hp->tw_hi[h] = unit_root((uint64_t)h << ASX_TW_LOG, F);
+    hp->tw_b.resize(M2);
+    for (int k2 = 0; k2 < M2; k2++) hp->tw_b[k2] = unit_root((uint64_t)M1 * k2, F);
+
+    hp->pos1_of_k1 = asx_position_table(hp->st1);
+    hp->k1_of_pos1.assign(M1, 0);
+    for (int k = 0; k < M1; k++) hp->k1_of_pos1[hp->pos1_of_k1[k]] = k;
+    hp->pos2_of_k2 = asx_position_table(hp->st2);
+    return "";
+}

@@ -1,0 +1,32 @@
+// csrc/plan_math.h — host-only planning arithmetic (no HIP calls): transform
+// length selection, the M = M1*M2 split, radix schedules, twiddle and index
+// tables.  Kept separate so the CPU test-suite can exercise it without a GPU
+// (tests/test_plan_math.py through the asx_planmath_* C entry points).
+#pragma once
+
+#include "asx_internal.h"
+
+#include <string>
+#include <vector>
+
+struct AsxHostPlan {
+    size_t N = 0;
+    uint32_t F = 0, M = 0, src_valid = 0;
+    int M1 = 0, M2 = 0, T = 0, logT = 0, ntiles = 0;
+    AsxStages st1{}, st2{};
+    std::vector<float2> tw1, tw2, tw_lo, tw_hi, tw_b;
+    std::vector<int> k1_of_pos1, pos1_of_k1, pos2_of_k2;
+};
+
+// LDS budgets that bound the split (bytes per workgroup).
+constexpr size_t ASX_LDS_COLS_MAX = 64 * 1024;  // M1 * T * 8
+constexpr size_t ASX_LDS_ROWS_MAX = 64 * 1024;  // 4 * M2 * 8
+constexpr size_t ASX_LDS_HW_MAX = 160 * 1024;   // what one gfx950 workgroup may declare (overrides only)
+
+bool asx_is_smooth(uint64_t n);                 // only factors 2, 3, 5
+uint64_t asx_next_smooth_even(uint64_t n);
+// Fills *plan for sample_len N. `split_override` may be "" or "M1xM2xT".
+// Returns "" on success, else an error message.
+std::string asx_host_plan_build(size_t N, const char *split_override, AsxHostPlan *plan);
+bool asx_make_stages(int n, AsxStages *st);
+std::vector<int> asx_position_table(const AsxStages &st); // pos[k] = slot of X[k] after the DIF transform

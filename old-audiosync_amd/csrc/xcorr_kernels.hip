@@ -1,0 +1,518 @@
+// csrc/xcorr_kernels.hip — the gfx950 kernels of the cross-correlation path.
+//
+// Pipeline for one pair (reference: src/cross_correlation.c:133-307):
+//
+//   k_fwd_cols   packs source / zero-padded sample as complex (z[j] = x[2j] + i x[2j+1]),
+//                column transforms of length M1 in LDS, four-step twiddle      (:159-166, :34-39)
+//   k_rows       row transforms of length M2 of BOTH spectra, real-FFT untangling,
+//                X * conj(Y), inverse real-FFT tangling, inverse row transforms,
+//                inverse four-step twiddle -- all inside LDS                    (:232-233, :237-239)
+//   k_inv_cols   inverse column transforms, |.|-argmax with the reference's exact
+//                tie/sign/NaN rules, r never written to HBM                     (:52-67, :242)
+//   k_finalize   per-pair reduction of the tile partials, lag wrap, segments   (:256-271)
+//   k_pearson_*  five float64 sums over the compared segments, coefficient,
+//                NaN gate                                                       (:74-116, :272-276)
+//
+// The transforms are memory-bound (about 6 flop/byte); nothing here uses MFMA.
+#include "asx_internal.h"
+#include "lds_fft.h"
+
+#include <math.h>
+
+extern __shared__ __attribute__((aligned(16))) float2 asx_lds[];
+
+// w_F^p for p < F from the two-level table (one complex multiply, ~1.5e-7 accurate).
+__device__ __forceinline__ float2 tw_F(const AsxDev &P, uint32_t p)
+{
+    const float2 lo = P.tw_lo[p & (ASX_TW_LO - 1u)];
+    const float2 hi = P.tw_hi[p >> ASX_TW_LOG];
+    return cmul(lo, hi);
+}
+
+// ---------------------------------------------------------------------------
+// k_fwd_cols: grid (ntiles, 2, npairs).  blockIdx.y: 0 = source, 1 = sample.
+// LDS tile: [M1][T] float2 (row pitch T, T a power of two), transform along rows.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(ASX_THREADS) void k_fwd_cols(AsxDev P, const float *__restrict__ src,
+                                                           const float *__restrict__ smp,
+                                                           float2 *__restrict__ zxa,
+                                                           float2 *__restrict__ zya)
+{
+    const int tile = blockIdx.x;
+    const bool is_smp = blockIdx.y != 0;
+    const size_t pair = blockIdx.z;
+    const int T = P.T, logT = P.logT, M1 = P.M1, M2 = P.M2;
+    const int c0 = tile * T;
+
+    const float *in = is_smp ? smp + pair * (size_t)P.N : src + pair * (size_t)P.src_period;
+    const uint32_t valid = is_smp ? P.N : P.src_valid;      // real samples that are not zero padding
+    const uint32_t period = is_smp ? P.N : P.src_period;    // source may be periodically extended
+    float2 *out = (is_smp ? zya : zxa) + pair * (size_t)P.M;
+    const bool vec_ok = ((reinterpret_cast<uintptr_t>(in) & 7u) == 0);
+
+    const int nelem = M1 << logT;
+    for (int e = threadIdx.x; e < nelem; e += ASX_THREADS) {
+        const int c = e & (T - 1), j1 = e >> logT;
+        const int j2 = c0 + c;
+        float2 v = make_float2(0.f, 0.f);
+        if (j2 < M2) {
+            const uint32_t i0 = 2u * ((uint32_t)j1 * (uint32_t)M2 + (uint32_t)j2);
+            if (vec_ok && i0 + 1u < valid && i0 + 1u < period) {
+                v = *reinterpret_cast<const float2 *>(in + i0);
+            } else {
+                if (i0 < valid) v.x = in[i0 < period ? i0 : i0 - period];
+                if (i0 + 1u < valid) v.y = in[i0 + 1u < period ? i0 + 1u : i0 + 1u - period];
+            }
+        }
+        asx_lds[e] = v;
+    }
+    __syncthreads();
+    lds_fft<false, true>(asx_lds, P.st1, T, logT, T, 1, P.tw1);
+
+    // slot p1 holds frequency k1 = k1_of_pos1[p1]; it stays in that slot in HBM.
+    for (int e = threadIdx.x; e < nelem; e += ASX_THREADS) {
+        const int c = e & (T - 1), p1 = e >> logT;
+        const int j2 = c0 + c;
+        if (j2 < M2) {
+            const uint32_t k1 = (uint32_t)P.k1_of_pos1[p1];
+            const float2 w = tw_F(P, 2u * k1 * (uint32_t)j2); // w_M^(k1*j2)
+            out[(size_t)p1 * M2 + j2] = cmul(asx_lds[e], w);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_rows: grid (M1/2 + 1, npairs).  Block rp handles spectrum rows k1 = rp and
+// m1 = M1 - rp (the rows that hold each other's k <-> M-k partners).
+// LDS: 4 rows of pitch M2: [Xa, Ya, Xb, Yb]; self-paired rows use [Xa, Ya].
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void combine_pair(float2 ax, float2 bx, float2 ay, float2 by, float2 w,
+                                             float2 &Gk, float2 &Gm)
+{
+    // real-FFT untangling: E = (a + conj b)/2, O = -i (a - conj b)/2, X[k] = E + w O,
+    // X[M-k] = conj(E - w O)
+    const float2 Ex = make_float2(0.5f * (ax.x + bx.x), 0.5f * (ax.y - bx.y));
+    const float2 Ox = make_float2(0.5f * (ax.y + bx.y), -0.5f * (ax.x - bx.x));
+    const float2 Ey = make_float2(0.5f * (ay.x + by.x), 0.5f * (ay.y - by.y));
+    const float2 Oy = make_float2(0.5f * (ay.y + by.y), -0.5f * (ay.x - by.x));
+    const float2 wOx = cmul(w, Ox), wOy = cmul(w, Oy);
+    const float2 Xk = cadd(Ex, wOx), Xm = cconj(csub(Ex, wOx));
+    const float2 Yk = cadd(Ey, wOy), Ym = cconj(csub(Ey, wOy));
+    // src/cross_correlation.c:232-233: arr1[i] *= conj(arr2[i])
+    const float2 Pk = cmulc(Xk, Yk), Pm = cmulc(Xm, Ym);
+    // inverse tangling: G[k] = (P[k] + conj P[M-k]) + i conj(w) (P[k] - conj P[M-k])
+    const float2 S = cadd(Pk, cconj(Pm)), D = csub(Pk, cconj(Pm));
+    const float2 V = cmulc(D, w);
+    Gk = make_float2(S.x - V.y, S.y + V.x);
+    Gm = make_float2(S.x + V.y, V.x - S.y);
+}
+
+__global__ __launch_bounds__(ASX_THREADS) void k_rows(AsxDev P, const float2 *__restrict__ zxa,
+                                                       const float2 *__restrict__ zya,
+                                                       float2 *__restrict__ ga)
+{
+    const int M1 = P.M1, M2 = P.M2;
+    const int k1 = blockIdx.x;
+    const int m1 = (M1 - k1) % M1;
+    const bool self = (k1 == m1);
+    const size_t pair = blockIdx.y;
+    const int pa = P.pos1_of_k1[k1], pb = P.pos1_of_k1[m1];
+    const int pitch = M2;
+    float2 *Xa = asx_lds, *Ya = asx_lds + pitch, *Xb = asx_lds + 2 * pitch, *Yb = asx_lds + 3 * pitch;
+
+    const float2 *gx = zxa + pair * (size_t)P.M, *gy = zya + pair * (size_t)P.M;
+    for (int j2 = threadIdx.x; j2 < M2; j2 += ASX_THREADS) {
+        Xa[j2] = gx[(size_t)pa * M2 + j2];
+        Ya[j2] = gy[(size_t)pa * M2 + j2];
+        if (!self) {
+            Xb[j2] = gx[(size_t)pb * M2 + j2];
+            Yb[j2] = gy[(size_t)pb * M2 + j2];
+        }
+    }
+    __syncthreads();
+    lds_fft<false, false>(asx_lds, P.st2, self ? 2 : 4, 0, 1, pitch, P.tw2);
+
+    // ---- spectral combine, in place: G[k] -> Xa slot, G[M-k] -> Xb (or Xa) slot ----
+    const float2 wA = tw_F(P, (uint32_t)k1); // w_F^k1, block-uniform
+    if (!self) {
+        for (int k2 = threadIdx.x; k2 < M2; k2 += ASX_THREADS) {
+            const int sa = P.pos2_of_k2[k2], sb = P.pos2_of_k2[M2 - 1 - k2];
+            const float2 w = cmul(wA, P.tw_b[k2]); // w_F^(k1 + M1*k2)
+            float2 Gk, Gm;
+            combine_pair(Xa[sa], Xb[sb], Ya[sa], Yb[sb], w, Gk, Gm);
+            Xa[sa] = Gk;
+            Xb[sb] = Gm;
+        }
+    } else if (k1 == 0) {
+        for (int k2 = threadIdx.x; k2 <= M2 / 2; k2 += ASX_THREADS) {
+            if (k2 == 0) {
+                // DC and Nyquist bins are real: X[0] = Re Z0 + Im Z0, X[M] = Re Z0 - Im Z0
+                const float2 zx = Xa[0], zy = Ya[0];
+                const float P0 = (zx.x + zx.y) * (zy.x + zy.y);
+                const float PM = (zx.x - zx.y) * (zy.x - zy.y);
+                Xa[0] = make_float2(P0 + PM, P0 - PM);
+            } else {
+                const int m2 = M2 - k2;
+                const int sa = P.pos2_of_k2[k2], sb = P.pos2_of_k2[m2];
+                float2 Gk, Gm;
+                combine_pair(Xa[sa], Xa[sb], Ya[sa], Ya[sb], P.tw_b[k2], Gk, Gm);
+                Xa[sa] = Gk;
+                if (m2 != k2) Xa[sb] = Gm;
+            }
+        }
+    } else { // k1 == M1/2, M1 even
+        for (int k2 = threadIdx.x; k2 < (M2 + 1) / 2; k2 += ASX_THREADS) {
+            const int m2 = M2 - 1 - k2;
+            const int sa = P.pos2_of_k2[k2], sb = P.pos2_of_k2[m2];
+            const float2 w = cmul(wA, P.tw_b[k2]);
+            float2 Gk, Gm;
+            combine_pair(Xa[sa], Xa[sb], Ya[sa], Ya[sb], w, Gk, Gm);
+            Xa[sa] = Gk;
+            if (m2 != k2) Xa[sb] = Gm;
+        }
+    }
+    __syncthreads();
+
+    // inverse row transforms of G (slots 0 and 2), digit-reversed in -> natural j2 out
+    lds_fft<true, false>(asx_lds, P.st2, self ? 1 : 2, 0, 1, 2 * pitch, P.tw2);
+
+    float2 *go = ga + pair * (size_t)P.M;
+    for (int j2 = threadIdx.x; j2 < M2; j2 += ASX_THREADS) {
+        const float2 wa = tw_F(P, 2u * (uint32_t)k1 * (uint32_t)j2); // conj(w_M^(k1*j2)) applied below
+        go[(size_t)pa * M2 + j2] = cmulc(Xa[j2], wa);
+        if (!self) {
+            const float2 wb = tw_F(P, 2u * (uint32_t)m1 * (uint32_t)j2);
+            go[(size_t)pb * M2 + j2] = cmulc(Xb[j2], wb);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// peak search helpers (src/cross_correlation.c:52-67)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ asx_peak_t peak_pack(float value, uint32_t idx)
+{
+    // key(0) = arr[0] SIGNED (:56), key(i) = fabs(arr[i]) (:59).  NaN never wins (:60),
+    // except that a NaN at index 0 is never beaten.
+    float key;
+    if (idx == 0u) {
+        key = (value != value) ? INFINITY : (value + 0.0f); // -0.0 -> +0.0 so it ties with |0|
+    } else {
+        key = fabsf(value);
+        if (key != key) key = -INFINITY;
+    }
+    uint32_t b = __float_as_uint(key);
+    b = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+    return ((asx_peak_t)b << 32) | (asx_peak_t)(0xFFFFFFFFu - idx);
+}
+
+__device__ __forceinline__ asx_peak_t peak_max(asx_peak_t a, asx_peak_t b) { return a > b ? a : b; }
+
+__device__ __forceinline__ asx_peak_t wave_peak_max(asx_peak_t v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const asx_peak_t o = __shfl_xor(v, off, 64);
+        v = peak_max(v, o);
+    }
+    return v;
+}
+
+// block-wide max; result valid in thread 0.  `scratch` = 4 entries of LDS.
+__device__ __forceinline__ asx_peak_t block_peak_max(asx_peak_t v, asx_peak_t *scratch)
+{
+    v = wave_peak_max(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) scratch[wave] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < ASX_THREADS / 64; w++) v = peak_max(v, scratch[w]);
+    }
+    return v;
+}
+
+// ---------------------------------------------------------------------------
+// k_inv_cols: grid (ntiles, npairs).  Inverse column transforms; the time-domain
+// correlation r[2j] = Re g[j], r[2j+1] = Im g[j] only lives in LDS/registers.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(ASX_THREADS) void k_inv_cols(AsxDev P, const float2 *__restrict__ ga,
+                                                           asx_peak_t *__restrict__ partials,
+                                                           float *__restrict__ r_out)
+{
+    __shared__ asx_peak_t red[ASX_THREADS / 64];
+    const int tile = blockIdx.x;
+    const size_t pair = blockIdx.y;
+    const int T = P.T, logT = P.logT, M1 = P.M1, M2 = P.M2;
+    const int c0 = tile * T;
+    const float2 *in = ga + pair * (size_t)P.M;
+
+    const int nelem = M1 << logT;
+    for (int e = threadIdx.x; e < nelem; e += ASX_THREADS) {
+        const int c = e & (T - 1), p1 = e >> logT;
+        const int j2 = c0 + c;
+        asx_lds[e] = (j2 < M2) ? in[(size_t)p1 * M2 + j2] : make_float2(0.f, 0.f);
+    }
+    __syncthreads();
+    lds_fft<true, true>(asx_lds, P.st1, T, logT, T, 1, P.tw1);
+
+    asx_peak_t best = 0;
+    for (int e = threadIdx.x; e < nelem; e += ASX_THREADS) {
+        const int c = e & (T - 1), j1 = e >> logT;
+        const int j2 = c0 + c;
+        if (j2 < M2) {
+            const uint32_t i0 = 2u * ((uint32_t)j1 * (uint32_t)M2 + (uint32_t)j2);
+            const float2 g = asx_lds[e];
+            if (i0 < P.nout) {
+                best = peak_max(best, peak_pack(g.x, i0));
+                if (r_out) r_out[pair * (size_t)P.nout + i0] = g.x;
+            }
+            if (i0 + 1u < P.nout) {
+                best = peak_max(best, peak_pack(g.y, i0 + 1u));
+                if (r_out) r_out[pair * (size_t)P.nout + i0 + 1u] = g.y;
+            }
+        }
+    }
+    best = block_peak_max(best, red);
+    if (threadIdx.x == 0) partials[pair * (size_t)P.ntiles + tile] = best;
+}
+
+// ---------------------------------------------------------------------------
+// k_finalize: grid (npairs).  Reduce tile partials, wrap the lag, pick segments.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(ASX_THREADS) void k_finalize(AsxDev P, const asx_peak_t *__restrict__ partials,
+                                                           AsxSeg *__restrict__ seg)
+{
+    __shared__ asx_peak_t red[ASX_THREADS / 64];
+    const size_t pair = blockIdx.x;
+    asx_peak_t best = 0;
+    for (int t = threadIdx.x; t < P.ntiles; t += ASX_THREADS)
+        best = peak_max(best, partials[pair * (size_t)P.ntiles + t]);
+    best = block_peak_max(best, red);
+    if (threadIdx.x == 0) {
+        const uint32_t peak = 0xFFFFFFFFu - (uint32_t)(best & 0xFFFFFFFFull);
+        const uint32_t N = P.N;
+        AsxSeg s;
+        s.peak = peak;
+        if (peak >= N) {
+            // src/cross_correlation.c:256-263: lag = (lag % N) - N; source[0 .. N+lag), sample[-lag .. N)
+            const long long l = (long long)(peak % N) - (long long)N;
+            s.lag = l;
+            s.src_off = 0;
+            s.smp_off = (uint32_t)(-l);
+            s.len = (uint32_t)((long long)N + l);
+        } else {
+            // :264-271: source[lag .. lag+N), sample[0 .. N)
+            s.lag = (long long)peak;
+            s.src_off = peak;
+            s.smp_off = 0;
+            s.len = N;
+        }
+        seg[pair] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Pearson coefficient (src/cross_correlation.c:74-116).  One streaming pass with
+// float64 accumulators: cov = Sxy - Sx*Sy/n, etc.  The reduction tree is fixed
+// (block-partition by index, wave butterflies), so identical segments give
+// bit-identical Sxx, Syy, Sxy and therefore exactly +-1.0.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+template <typename TIn>
+__global__ __launch_bounds__(ASX_THREADS) void k_pearson_partial(const TIn *__restrict__ src,
+                                                                  const TIn *__restrict__ smp,
+                                                                  size_t src_pitch, size_t smp_pitch,
+                                                                  uint32_t basis_len,
+                                                                  const AsxSeg *__restrict__ seg,
+                                                                  double *__restrict__ psums)
+{
+    __shared__ double red[5][ASX_THREADS / 64];
+    const size_t pair = blockIdx.y;
+    const AsxSeg s = seg[pair];
+    const uint32_t chunk = (basis_len + ASX_PEARSON_BLOCKS - 1) / ASX_PEARSON_BLOCKS;
+    const uint64_t lo = (uint64_t)blockIdx.x * chunk;
+    uint64_t hi = lo + chunk;
+    if (hi > s.len) hi = s.len;
+    const TIn *x = src + pair * src_pitch + s.src_off;
+    const TIn *y = smp + pair * smp_pitch + s.smp_off;
+    double sx = 0, sy = 0, sxy = 0, sxx = 0, syy = 0;
+    for (uint64_t i = lo + threadIdx.x; i < hi; i += ASX_THREADS) {
+        const double a = (double)x[i], b = (double)y[i];
+        sx += a;
+        sy += b;
+        sxy += a * b;
+        sxx += a * a;
+        syy += b * b;
+    }
+    double v[5] = { wave_sum(sx), wave_sum(sy), wave_sum(sxy), wave_sum(sxx), wave_sum(syy) };
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0)
+        for (int q = 0; q < 5; q++) red[q][wave] = v[q];
+    __syncthreads();
+    if (threadIdx.x < 5) {
+        double t = red[threadIdx.x][0];
+        for (int w = 1; w < ASX_THREADS / 64; w++) t += red[threadIdx.x][w];
+        psums[(pair * ASX_PEARSON_BLOCKS + blockIdx.x) * 5 + threadIdx.x] = t;
+    }
+}
+
+// grid (npairs), one wave per pair: lane b owns partial block b.
+__global__ __launch_bounds__(64) void k_pearson_final(const AsxSeg *__restrict__ seg,
+                                                       const double *__restrict__ psums,
+                                                       int64_t *__restrict__ lag,
+                                                       double *__restrict__ coef,
+                                                       int32_t *__restrict__ ret)
+{
+    const size_t pair = blockIdx.x;
+    const double *p = psums + (pair * ASX_PEARSON_BLOCKS + threadIdx.x) * 5;
+    const double sx = wave_sum(p[0]), sy = wave_sum(p[1]), sxy = wave_sum(p[2]);
+    const double sxx = wave_sum(p[3]), syy = wave_sum(p[4]);
+    if (threadIdx.x == 0) {
+        const AsxSeg s = seg[pair];
+        const double n = (double)s.len;
+        const double cov = sxy - sx * sy / n;
+        const double vx = sxx - sx * sx / n;
+        const double vy = syy - sy * sy / n;
+        const double c = cov / sqrt(vx * vy);
+        if (lag) lag[pair] = s.lag;
+        coef[pair] = c;
+        // src/cross_correlation.c:276: NaN coefficient -> return -1 (outputs already written)
+        if (ret) ret[pair] = (c != c) ? -1 : 0;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// double -> float conversion of the reference's f64 buffers
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(ASX_THREADS) void k_cvt_f64_f32(const double *__restrict__ in,
+                                                              float *__restrict__ out, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * ASX_THREADS + threadIdx.x; i < n;
+         i += (size_t)gridDim.x * ASX_THREADS)
+        out[i] = (float)in[i];
+}
+
+// ---------------------------------------------------------------------------
+// synthetic pairs: bit-identical to oracle_synth_pair (oracle/xcorr_oracle.c)
+// ---------------------------------------------------------------------------
+__host__ __device__ __forceinline__ uint64_t mix64(uint64_t x)
+{
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__host__ __device__ __forceinline__ uint64_t stream_key(uint64_t seed, uint64_t pair, uint64_t stream)
+{
+    return mix64(mix64(seed) + 0x632BE59BD9B4E019ull * (pair + 1) + stream);
+}
+__device__ __forceinline__ float u24(uint64_t h)
+{
+    const int32_t v = (int32_t)(h >> 40) - (1 << 23);
+    return (float)v * (1.0f / 8388608.0f);
+}
+__device__ __forceinline__ float z22(uint64_t key, uint64_t n)
+{
+    const uint64_t h1 = mix64(key + 2 * n), h2 = mix64(key + 2 * n + 1);
+    const int32_t a = (int32_t)(h1 >> 42), b = (int32_t)((h1 >> 20) & 0x3FFFFF);
+    const int32_t c = (int32_t)(h2 >> 42), d = (int32_t)((h2 >> 20) & 0x3FFFFF);
+    const int32_t v = a + b + c + d - (1 << 23);
+    return (float)v * (1.0f / 4194304.0f);
+}
+
+__global__ __launch_bounds__(ASX_THREADS) void k_synth(uint64_t seed, uint64_t first_pair, uint32_t N,
+                                                        float amp, float *__restrict__ src,
+                                                        float *__restrict__ smp,
+                                                        int64_t *__restrict__ true_lag)
+{
+    const uint64_t pair = first_pair + blockIdx.y;
+    const uint64_t ks = stream_key(seed, pair, 1), kn = stream_key(seed, pair, 2);
+    const uint64_t kl = stream_key(seed, pair, 3);
+    const int64_t span = (int64_t)(3ull * N / 4);
+    const int64_t lag = (int64_t)(mix64(kl) % (uint64_t)(2 * span + 1)) - span;
+    float *s = src + (size_t)blockIdx.y * 2 * N;
+    float *t = smp + (size_t)blockIdx.y * N;
+    for (uint32_t i = blockIdx.x * ASX_THREADS + threadIdx.x; i < 2u * N; i += gridDim.x * ASX_THREADS) {
+        s[i] = u24(mix64(ks + N + i));
+        if (i < N) {
+            const float sig = 0.5f * u24(mix64(ks + (uint64_t)((int64_t)N + (int64_t)i + lag)));
+            t[i] = __fadd_rn(sig, __fmul_rn(amp, z22(kn, i)));
+        }
+    }
+    if (true_lag && blockIdx.x == 0 && threadIdx.x == 0) true_lag[blockIdx.y] = lag;
+}
+
+// ---------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------
+size_t asx_lds_bytes_cols(const AsxDev &P) { return (size_t)P.M1 * P.T * sizeof(float2); }
+size_t asx_lds_bytes_rows(const AsxDev &P) { return (size_t)4 * P.M2 * sizeof(float2); }
+
+void asx_launch_fwd_cols(const AsxDev &P, const float *src, const float *smp, float2 *zxa,
+                         float2 *zya, int npairs, hipStream_t s)
+{
+    dim3 grid(P.ntiles, 2, npairs);
+    hipLaunchKernelGGL(k_fwd_cols, grid, dim3(ASX_THREADS), asx_lds_bytes_cols(P), s, P, src, smp, zxa, zya);
+}
+
+void asx_launch_rows(const AsxDev &P, const float2 *zxa, const float2 *zya, float2 *ga, int npairs,
+                     hipStream_t s)
+{
+    dim3 grid(P.M1 / 2 + 1, npairs);
+    hipLaunchKernelGGL(k_rows, grid, dim3(ASX_THREADS), asx_lds_bytes_rows(P), s, P, zxa, zya, ga);
+}
+
+void asx_launch_inv_cols(const AsxDev &P, const float2 *ga, asx_peak_t *partials, float *r_out,
+                         int npairs, hipStream_t s)
+{
+    dim3 grid(P.ntiles, npairs);
+    hipLaunchKernelGGL(k_inv_cols, grid, dim3(ASX_THREADS), asx_lds_bytes_cols(P), s, P, ga, partials, r_out);
+}
+
+void asx_launch_finalize(const AsxDev &P, const asx_peak_t *partials, AsxSeg *seg, int npairs,
+                         hipStream_t s)
+{
+    hipLaunchKernelGGL(k_finalize, dim3(npairs), dim3(ASX_THREADS), 0, s, P, partials, seg);
+}
+
+void asx_launch_pearson_f32(const float *src, const float *smp, size_t src_pitch, size_t smp_pitch,
+                            uint32_t basis_len, const AsxSeg *seg, double *psums, int64_t *lag,
+                            double *coef, int32_t *ret, int npairs, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_pearson_partial<float>, dim3(ASX_PEARSON_BLOCKS, npairs), dim3(ASX_THREADS), 0, s,
+                       src, smp, src_pitch, smp_pitch, basis_len, seg, psums);
+    hipLaunchKernelGGL(k_pearson_final, dim3(npairs), dim3(64), 0, s, seg, psums, lag, coef, ret);
+}
+
+void asx_launch_pearson_f64(const double *src, const double *smp, size_t src_pitch, size_t smp_pitch,
+                            uint32_t basis_len, const AsxSeg *seg, double *psums, int64_t *lag,
+                            double *coef, int32_t *ret, int npairs, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_pearson_partial<double>, dim3(ASX_PEARSON_BLOCKS, npairs), dim3(ASX_THREADS), 0, s,
+                       src, smp, src_pitch, smp_pitch, basis_len, seg, psums);
+    hipLaunchKernelGGL(k_pearson_final, dim3(npairs), dim3(64), 0, s, seg, psums, lag, coef, ret);
+}
+
+void asx_launch_cvt_f64_f32(const double *in, float *out, size_t n, hipStream_t s)
+{
+    size_t blocks = (n + ASX_THREADS - 1) / ASX_THREADS;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(k_cvt_f64_f32, dim3((unsigned)blocks), dim3(ASX_THREADS), 0, s, in, out, n);
+}
+
+void asx_launch_synth(uint64_t seed, uint64_t first_pair, size_t count, uint32_t N, int noise_shift,
+                      float *src, float *smp, int64_t *true_lag, hipStream_t s)
+{
+    unsigned bx = (2u * N + ASX_THREADS - 1) / ASX_THREADS;
+    if (bx > 1024) bx = 1024;
+    const float amp = ldexpf(1.0f, -noise_shift);
+    hipLaunchKernelGGL(k_synth, dim3(bx, (unsigned)count), dim3(ASX_THREADS), 0, s, seed, first_pair, N,
+                       amp, src, smp, true_lag);
+}

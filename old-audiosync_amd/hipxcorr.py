@@ -1,0 +1,259 @@
+"""ctypes view of libaudiosync_hip.so (the C-ABI in include/audiosync/xcorr_hip.h)."""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libaudiosync_hip.so")
+_lib = None
+
+c_f32p = ctypes.POINTER(ctypes.c_float)
+c_f64p = ctypes.POINTER(ctypes.c_double)
+c_i64p = ctypes.POINTER(ctypes.c_int64)
+c_i32p = ctypes.POINTER(ctypes.c_int32)
+c_intp = ctypes.POINTER(ctypes.c_int)
+
+# every symbol include/audiosync/xcorr_hip.h declares (checked by tests/test_abi.py)
+ABI_SYMBOLS = [
+    "asx_device_count", "asx_last_error", "asx_abi_version", "asx_plan_create", "asx_plan_create_ex", "asx_plan_destroy",
+    "asx_plan_sample_len", "asx_plan_fft_len", "asx_plan_split", "asx_plan_group",
+    "asx_plan_workspace_bytes", "asx_xcorr_f64", "asx_xcorr_batch_f32", "asx_xcorr_batch_f32_dev",
+    "asx_xcorr_debug_r_dev", "asx_pearson_f64", "asx_synth_pairs_dev", "asx_plan_set_profiling",
+    "asx_plan_last_timings_ms", "asx_device_malloc", "asx_device_free", "asx_memcpy_h2d",
+    "asx_memcpy_d2h", "asx_stream_sync",
+]
+
+
+class AsxError(RuntimeError):
+    pass
+
+
+def lib():
+    """dlopen the HIP layer; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AsxError(LIB_PATH + " is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    L = ctypes.CDLL(LIB_PATH)
+    vp = ctypes.c_void_p
+    L.asx_device_count.restype = ctypes.c_int
+    L.asx_last_error.restype = ctypes.c_char_p
+    L.asx_abi_version.restype = ctypes.c_int
+    L.asx_plan_create.restype = vp
+    L.asx_plan_create.argtypes = [ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int]
+    L.asx_plan_create_ex.restype = vp
+    L.asx_plan_create_ex.argtypes = [ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, ctypes.c_char_p]
+    L.asx_plan_destroy.restype = None
+    L.asx_plan_destroy.argtypes = [vp]
+    for name in ("asx_plan_sample_len", "asx_plan_fft_len", "asx_plan_group", "asx_plan_workspace_bytes"):
+        getattr(L, name).restype = ctypes.c_size_t
+        getattr(L, name).argtypes = [vp]
+    L.asx_plan_split.restype = ctypes.c_int
+    L.asx_plan_split.argtypes = [vp, c_intp, c_intp, c_intp]
+    L.asx_xcorr_f64.restype = ctypes.c_int
+    L.asx_xcorr_f64.argtypes = [vp, c_f64p, c_f64p, ctypes.POINTER(ctypes.c_long), c_f64p]
+    L.asx_xcorr_batch_f32.restype = ctypes.c_int
+    L.asx_xcorr_batch_f32.argtypes = [vp, c_f32p, c_f32p, ctypes.c_size_t, c_i64p, c_f64p, c_i32p]
+    L.asx_xcorr_batch_f32_dev.restype = ctypes.c_int
+    L.asx_xcorr_batch_f32_dev.argtypes = [vp, vp, vp, ctypes.c_size_t, vp, vp, vp, vp]
+    L.asx_xcorr_debug_r_dev.restype = ctypes.c_int
+    L.asx_xcorr_debug_r_dev.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
+    L.asx_pearson_f64.restype = ctypes.c_int
+    L.asx_pearson_f64.argtypes = [c_f64p, c_f64p, ctypes.c_size_t, ctypes.c_int, c_f64p]
+    L.asx_synth_pairs_dev.restype = ctypes.c_int
+    L.asx_synth_pairs_dev.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_size_t, ctypes.c_size_t,
+                                      ctypes.c_int, vp, vp, vp, vp]
+    L.asx_plan_set_profiling.restype = ctypes.c_int
+    L.asx_plan_set_profiling.argtypes = [vp, ctypes.c_int]
+    L.asx_plan_last_timings_ms.restype = ctypes.c_int
+    L.asx_plan_last_timings_ms.argtypes = [vp, c_f32p]
+    L.asx_device_malloc.restype = vp
+    L.asx_device_malloc.argtypes = [ctypes.c_size_t, ctypes.c_int]
+    L.asx_device_free.restype = ctypes.c_int
+    L.asx_device_free.argtypes = [vp]
+    L.asx_memcpy_h2d.restype = ctypes.c_int
+    L.asx_memcpy_h2d.argtypes = [vp, vp, ctypes.c_size_t]
+    L.asx_memcpy_d2h.restype = ctypes.c_int
+    L.asx_memcpy_d2h.argtypes = [vp, vp, ctypes.c_size_t]
+    L.asx_stream_sync.restype = ctypes.c_int
+    L.asx_stream_sync.argtypes = [vp, vp]
+    # planning arithmetic (host only)
+    L.asx_planmath_describe.restype = ctypes.c_int
+    L.asx_planmath_describe.argtypes = [ctypes.c_size_t, ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint32),
+                                        ctypes.POINTER(ctypes.c_uint32), c_intp, c_intp, c_intp, c_intp,
+                                        c_intp, c_intp, c_intp]
+    L.asx_planmath_table.restype = ctypes.c_int
+    L.asx_planmath_table.argtypes = [ctypes.c_size_t, ctypes.c_char_p, ctypes.c_int, c_intp, ctypes.c_size_t]
+    L.asx_planmath_twiddles.restype = ctypes.c_int
+    L.asx_planmath_twiddles.argtypes = [ctypes.c_size_t, ctypes.c_char_p, ctypes.c_int, c_f32p, ctypes.c_size_t]
+    _lib = L
+    return L
+
+
+def _err():
+    return lib().asx_last_error().decode("utf-8", "replace")
+
+
+def abi_version():
+    return lib().asx_abi_version()
+
+
+def device_count():
+    return lib().asx_device_count()
+
+
+def _split_arg(split):
+    return split.encode() if split else None
+
+
+def planmath_describe(sample_len, split=None):
+    """host-only: what plan would be built for sample_len (no GPU needed)."""
+    F, valid = ctypes.c_uint32(), ctypes.c_uint32()
+    m1, m2, t, n1, n2 = (ctypes.c_int() for _ in range(5))
+    r1 = (ctypes.c_int * 16)()
+    r2 = (ctypes.c_int * 16)()
+    rc = lib().asx_planmath_describe(sample_len, _split_arg(split), F, valid, m1, m2, t, n1, r1, n2, r2)
+    if rc != 0:
+        raise AsxError(_err())
+    return {"F": F.value, "src_valid": valid.value, "M1": m1.value, "M2": m2.value, "T": t.value,
+            "radix1": list(r1[: n1.value]), "radix2": list(r2[: n2.value])}
+
+
+def planmath_table(sample_len, which, split=None):
+    d = planmath_describe(sample_len, split)
+    cap = max(d["M1"], d["M2"])
+    buf = (ctypes.c_int * cap)()
+    n = lib().asx_planmath_table(sample_len, _split_arg(split), which, buf, cap)
+    if n < 0:
+        raise AsxError(_err())
+    return np.array(buf[:n], dtype=np.int64)
+
+
+def planmath_twiddles(sample_len, which, split=None):
+    d = planmath_describe(sample_len, split)
+    cap = max(d["M1"], d["M2"], 2048, (d["F"] >> 11) + 2)
+    buf = np.zeros(2 * cap, dtype=np.float32)
+    n = lib().asx_planmath_twiddles(sample_len, _split_arg(split), which,
+                                    buf.ctypes.data_as(c_f32p), cap)
+    if n < 0:
+        raise AsxError(_err())
+    return buf[: 2 * n].view(np.complex64).copy()
+
+
+def pearson_f64(source_seg, sample_seg, device=-1):
+    a = np.ascontiguousarray(source_seg, dtype=np.float64)
+    b = np.ascontiguousarray(sample_seg, dtype=np.float64)
+    assert a.size == b.size
+    out = ctypes.c_double(0.0)
+    rc = lib().asx_pearson_f64(a.ctypes.data_as(c_f64p), b.ctypes.data_as(c_f64p), a.size, device,
+                               ctypes.byref(out))
+    if rc != 0:
+        raise AsxError(_err())
+    return out.value
+
+
+def synth_pairs_dev(seed, first_pair, count, sample_len, noise_shift, d_src, d_smp, d_lag=0, stream=0):
+    rc = lib().asx_synth_pairs_dev(seed, first_pair, count, sample_len, noise_shift, d_src, d_smp,
+                                   d_lag or None, stream or None)
+    if rc != 0:
+        raise AsxError(_err())
+
+
+class Plan:
+    """asx_plan: fixed sample_len, owns tables + HBM workspaces on one device."""
+
+    def __init__(self, sample_len, max_batch=1, device=-1, split=None):
+        self._h = lib().asx_plan_create_ex(int(sample_len), int(max_batch), int(device),
+                                           _split_arg(split))
+        if not self._h:
+            raise AsxError(_err())
+        self.sample_len = int(sample_len)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().asx_plan_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    @property
+    def fft_len(self):
+        return lib().asx_plan_fft_len(self._h)
+
+    @property
+    def group(self):
+        return lib().asx_plan_group(self._h)
+
+    @property
+    def workspace_bytes(self):
+        return lib().asx_plan_workspace_bytes(self._h)
+
+    @property
+    def split(self):
+        a, b, c = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        lib().asx_plan_split(self._h, a, b, c)
+        return a.value, b.value, c.value
+
+    def xcorr_f64(self, source, sample):
+        """the reference's calling convention: -> (ret, lag, coefficient)"""
+        s = np.ascontiguousarray(source, dtype=np.float64)
+        t = np.ascontiguousarray(sample, dtype=np.float64)
+        assert t.size == self.sample_len and s.size == 2 * self.sample_len
+        lag = ctypes.c_long(0)
+        coef = ctypes.c_double(0.0)
+        ret = lib().asx_xcorr_f64(self._h, s.ctypes.data_as(c_f64p), t.ctypes.data_as(c_f64p),
+                                  ctypes.byref(lag), ctypes.byref(coef))
+        return ret, lag.value, coef.value
+
+    def xcorr_batch_f32(self, source, sample):
+        """host float32 arrays [B,2N], [B,N] -> (lag int64[B], coef float64[B], ret int32[B])"""
+        s = np.ascontiguousarray(source, dtype=np.float32)
+        t = np.ascontiguousarray(sample, dtype=np.float32)
+        n = self.sample_len
+        batch = t.size // n
+        assert t.size == batch * n and s.size == 2 * n * batch
+        lag = np.zeros(batch, dtype=np.int64)
+        coef = np.zeros(batch, dtype=np.float64)
+        ret = np.zeros(batch, dtype=np.int32)
+        rc = lib().asx_xcorr_batch_f32(self._h, s.ctypes.data_as(c_f32p), t.ctypes.data_as(c_f32p), batch,
+                                       lag.ctypes.data_as(c_i64p), coef.ctypes.data_as(c_f64p),
+                                       ret.ctypes.data_as(c_i32p))
+        if rc != 0:
+            raise AsxError(_err())
+        return lag, coef, ret
+
+    def xcorr_batch_dev(self, d_src, d_smp, batch, d_lag, d_coef, d_ret, stream=0):
+        """raw device pointers (ints); asynchronous on `stream` (0 = the plan's own)"""
+        rc = lib().asx_xcorr_batch_f32_dev(self._h, d_src, d_smp, batch, d_lag or None, d_coef,
+                                           d_ret or None, stream or None)
+        if rc != 0:
+            raise AsxError(_err())
+
+    def debug_r_dev(self, d_src, d_smp, d_r, d_lag, d_coef, d_ret, stream=0):
+        rc = lib().asx_xcorr_debug_r_dev(self._h, d_src, d_smp, d_r, d_lag, d_coef, d_ret, stream or None)
+        if rc != 0:
+            raise AsxError(_err())
+
+    def set_profiling(self, on):
+        lib().asx_plan_set_profiling(self._h, 1 if on else 0)
+
+    def last_timings_ms(self):
+        out = (ctypes.c_float * 6)()
+        rc = lib().asx_plan_last_timings_ms(self._h, out)
+        if rc != 0:
+            raise AsxError(_err())
+        return dict(zip(("fwd_cols", "rows", "inv_cols", "finalize", "pearson", "total"), list(out)))
+
+    def sync(self, stream=0):
+        rc = lib().asx_stream_sync(self._h, stream or None)
+        if rc != 0:
+            raise AsxError(_err())

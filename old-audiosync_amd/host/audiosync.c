@@ -1,0 +1,251 @@
+/* host/audiosync.c — job state, control API and the growing-window loop.
+ *
+ * Mirrors the observable behaviour of the reference orchestrator
+ * (src/audiosync.c:36-138 for the globals/control functions, :166-284 for
+ * audiosync_run) with ONE difference: the two producers are not ffmpeg
+ * children (src/ffmpeg_pipe.c, out of scope) but threads copying from
+ * caller-provided memory (audiosync_set_feed) in the same 4096-frame steps and
+ * with the same signalling protocol (src/ffmpeg_pipe.c:63-149): signal
+ * interval_done when an interval boundary is crossed, honour PAUSED_ST /
+ * ABORT_ST between steps, zero-fill a short track and signal once more.
+ * The consumer side -- wait for both producers, cross_correlation() on the
+ * prefixes, first interval with coefficient >= MIN_CONFIDENCE wins, lag
+ * converted to milliseconds -- follows src/audiosync.c:226-259.
+ */
+#include <math.h>
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include <audiosync/audiosync.h>
+#include <audiosync/cross_correlation.h>
+
+volatile global_status_t global_status = IDLE_ST;
+volatile int global_debug = 0;
+pthread_mutex_t mutex = PTHREAD_MUTEX_INITIALIZER;
+pthread_cond_t interval_done = PTHREAD_COND_INITIALIZER;
+pthread_cond_t read_continue = PTHREAD_COND_INITIALIZER;
+
+/* 3, 6, 10, 15, 20, 30 seconds of sample; the source side is always twice that
+ * (src/audiosync.c:50-70). */
+#define N_INTERVALS 6
+static const size_t interv_sample[N_INTERVALS] = {
+    3 * SAMPLE_RATE, 6 * SAMPLE_RATE, 10 * SAMPLE_RATE,
+    15 * SAMPLE_RATE, 20 * SAMPLE_RATE, 30 * SAMPLE_RATE,
+};
+static const size_t interv_source[N_INTERVALS] = {
+    2 * 3 * SAMPLE_RATE, 2 * 6 * SAMPLE_RATE, 2 * 10 * SAMPLE_RATE,
+    2 * 15 * SAMPLE_RATE, 2 * 20 * SAMPLE_RATE, 2 * 30 * SAMPLE_RATE,
+};
+#define LEN_SAMPLE ((size_t) 30 * SAMPLE_RATE)
+#define LEN_SOURCE ((size_t) 2 * 30 * SAMPLE_RATE)
+#define FEED_STEP 4096 /* frames per producer step, src/ffmpeg_pipe.c BUFSIZE */
+
+void audiosync_abort()
+{
+    pthread_mutex_lock(&mutex);
+    global_status = ABORT_ST;
+    pthread_cond_broadcast(&interval_done);
+    pthread_cond_broadcast(&read_continue);
+    pthread_mutex_unlock(&mutex);
+}
+
+void audiosync_pause()
+{
+    pthread_mutex_lock(&mutex);
+    global_status = PAUSED_ST;
+    pthread_mutex_unlock(&mutex);
+}
+
+void audiosync_resume()
+{
+    pthread_mutex_lock(&mutex);
+    global_status = RUNNING_ST;
+    pthread_cond_broadcast(&read_continue);
+    pthread_mutex_unlock(&mutex);
+}
+
+global_status_t audiosync_status()
+{
+    pthread_mutex_lock(&mutex);
+    global_status_t now = global_status;
+    pthread_mutex_unlock(&mutex);
+    return now;
+}
+
+int audiosync_get_debug()
+{
+    pthread_mutex_lock(&mutex);
+    int now = global_debug;
+    pthread_mutex_unlock(&mutex);
+    return now;
+}
+
+void audiosync_set_debug(int do_debug)
+{
+    pthread_mutex_lock(&mutex);
+    global_debug = do_debug;
+    pthread_mutex_unlock(&mutex);
+}
+
+char *status_to_string(global_status_t status)
+{
+    switch (status) {
+    case IDLE_ST:    return "idle";
+    case RUNNING_ST: return "running";
+    case PAUSED_ST:  return "paused";
+    case ABORT_ST:   return "aborting";
+    default:         return "unknown";
+    }
+}
+
+int audiosync_setup(const char *stream_name)
+{
+    UNUSED(stream_name);
+    LOG("audiosync_setup: PulseAudio capture is out of scope of the MI355X build");
+    return -1;
+}
+
+/* ---- in-memory producers --------------------------------------------------- */
+struct feed {
+    const double *data;
+    size_t len;
+};
+static struct feed feed_source, feed_sample;
+static unsigned feed_frames_per_ms;
+
+int audiosync_set_feed(const double *source, size_t source_len, const double *sample,
+                       size_t sample_len, unsigned frames_per_ms)
+{
+    pthread_mutex_lock(&mutex);
+    feed_source.data = source; feed_source.len = source_len;
+    feed_sample.data = sample; feed_sample.len = sample_len;
+    feed_frames_per_ms = frames_per_ms;
+    pthread_mutex_unlock(&mutex);
+    return 0;
+}
+
+struct producer_args {
+    struct ffmpeg_data *out;
+    struct feed in;
+    unsigned frames_per_ms;
+};
+
+static void *producer(void *arg)
+{
+    struct producer_args *pa = arg;
+    struct ffmpeg_data *d = pa->out;
+    size_t interval = 0;
+    const size_t avail = pa->in.data ? (pa->in.len < d->total_len ? pa->in.len : d->total_len) : 0;
+
+    while (d->len < avail) {
+        size_t step = avail - d->len < FEED_STEP ? avail - d->len : FEED_STEP;
+        memcpy(d->buf + d->len, pa->in.data + d->len, step * sizeof(*d->buf));
+        if (pa->frames_per_ms) {
+            struct timespec ts = { 0, (long)(1000000.0 * step / pa->frames_per_ms) };
+            nanosleep(&ts, NULL);
+        }
+        pthread_mutex_lock(&mutex);
+        d->len += step;
+        if (interval < d->n_intervals && d->len >= d->intervals[interval]) {
+            pthread_cond_signal(&interval_done);
+            interval++;
+        }
+        /* pause / abort are observed between steps, like src/ffmpeg_pipe.c:99-134 */
+        while (global_status == PAUSED_ST) pthread_cond_wait(&read_continue, &mutex);
+        const int stop = (global_status == ABORT_ST);
+        pthread_mutex_unlock(&mutex);
+        if (stop) return NULL;
+    }
+    /* a short track: the tail reads as silence (src/ffmpeg_pipe.c:139-149) */
+    if (d->len < d->total_len) {
+        memset(d->buf + d->len, 0, (d->total_len - d->len) * sizeof(*d->buf));
+        pthread_mutex_lock(&mutex);
+        d->len = d->total_len;
+        pthread_cond_signal(&interval_done);
+        pthread_mutex_unlock(&mutex);
+    }
+    return NULL;
+}
+
+int audiosync_run(const char *yt_title, long *lag)
+{
+    DEBUG_ASSERT(yt_title); DEBUG_ASSERT(lag);
+    DEBUG_ASSERT(global_status == IDLE_ST);
+
+    global_status = RUNNING_ST;
+    int ret = -1;
+    double confidence;
+    pthread_t cap_th, down_th;
+    int cap_started = 0, down_started = 0;
+    double *sample = malloc(LEN_SAMPLE * sizeof(*sample));
+    double *source = malloc(LEN_SOURCE * sizeof(*source));
+    struct ffmpeg_data cap_args = {
+        .title = "", .buf = sample, .len = 0, .total_len = LEN_SAMPLE,
+        .intervals = interv_sample, .n_intervals = N_INTERVALS,
+    };
+    struct ffmpeg_data down_args = {
+        .title = yt_title, .buf = source, .len = 0, .total_len = LEN_SOURCE,
+        .intervals = interv_source, .n_intervals = N_INTERVALS,
+    };
+    struct producer_args cap_pa, down_pa;
+
+    if (sample == NULL || source == NULL) {
+        perror("audiosync: track buffer malloc failed");
+        goto finish;
+    }
+    pthread_mutex_lock(&mutex);
+    cap_pa.out = &cap_args; cap_pa.in = feed_sample; cap_pa.frames_per_ms = feed_frames_per_ms;
+    down_pa.out = &down_args; down_pa.in = feed_source; down_pa.frames_per_ms = feed_frames_per_ms;
+    pthread_mutex_unlock(&mutex);
+    if (cap_pa.in.data == NULL || down_pa.in.data == NULL) {
+        /* nothing to record or download: the reference's producers fail and abort the job */
+        LOG("no feed configured (audiosync_set_feed); aborting");
+        goto finish;
+    }
+    if (pthread_create(&cap_th, NULL, &producer, &cap_pa) != 0) {
+        perror("audiosync: pthread_create for cap_th failed");
+        goto finish;
+    }
+    cap_started = 1;
+    if (pthread_create(&down_th, NULL, &producer, &down_pa) != 0) {
+        perror("audiosync: pthread_create for down_th failed");
+        goto finish;
+    }
+    down_started = 1;
+
+    LOG("starting interval loop");
+    for (size_t i = 0; i < N_INTERVALS; i++) {
+        pthread_mutex_lock(&mutex);
+        while ((cap_args.len < interv_sample[i] || down_args.len < interv_source[i])
+               && global_status != ABORT_ST) {
+            pthread_cond_wait(&interval_done, &mutex);
+        }
+        const int aborted = (global_status == ABORT_ST);
+        const size_t have_cap = cap_args.len, have_down = down_args.len;
+        pthread_mutex_unlock(&mutex);
+        if (aborted) break;
+
+        LOG("next interval (%ld): cap=%ld down=%ld", (long) i, (long) have_cap, (long) have_down);
+
+        if (cross_correlation(source, sample, interv_sample[i], lag, &confidence) < 0)
+            continue;
+        if (confidence >= MIN_CONFIDENCE) {
+            *lag = round((double) (*lag) * FRAMES_TO_MS);
+            ret = 0;
+            break;
+        }
+    }
+
+finish:
+    audiosync_abort();
+    if (cap_started) pthread_join(cap_th, NULL);
+    if (down_started) pthread_join(down_th, NULL);
+    free(sample);
+    free(source);
+    global_status = IDLE_ST;
+    LOG("finished run");
+    return ret;
+}

@@ -1,0 +1,113 @@
+/* host/cross_correlation.c — the reference's hot-path API on the MI355X layer.
+ *
+ * Plain C.  cross_correlation() and pearson_coefficient() keep the signatures
+ * and the error behaviour of the reference (src/cross_correlation.c:74-75,
+ * 133-135; contract in SURVEY.md section 8b) and forward to the gfx950 C-ABI
+ * (audiosync/xcorr_hip.h).  What the reference does per call -- FFTW plans
+ * under cc_mutex (:33-36), four aligned allocations (:159,187-201) -- becomes a
+ * small cache of asx_plan objects keyed by sample_len, guarded by one mutex, so
+ * that the six interval lengths of src/audiosync.c:50-57 each build their
+ * tables and HBM workspaces once.
+ *
+ * There is no CPU path here: without a working GPU both functions fail the way
+ * the reference fails on an allocation error (-1 / NaN, message on stderr).
+ */
+#include <math.h>
+#include <pthread.h>
+#include <stdio.h>
+
+#include <audiosync/audiosync.h>
+#include <audiosync/cross_correlation.h>
+#include <audiosync/xcorr_hip.h>
+
+#define PLAN_CACHE_SLOTS 8
+
+struct cached_plan {
+    size_t sample_len;
+    asx_plan *plan;
+    unsigned long last_use;
+};
+
+/* Concurrent callers are legal in the reference (SURVEY.md 8b "Threading"); the
+ * cache is shared, each plan serialises its own use internally. */
+static pthread_mutex_t cache_mutex = PTHREAD_MUTEX_INITIALIZER;
+static struct cached_plan cache[PLAN_CACHE_SLOTS];
+static unsigned long use_clock;
+
+static asx_plan *plan_for(size_t sample_len)
+{
+    asx_plan *found = NULL;
+    pthread_mutex_lock(&cache_mutex);
+    int victim = 0;
+    for (int i = 0; i < PLAN_CACHE_SLOTS; i++) {
+        if (cache[i].plan && cache[i].sample_len == sample_len) {
+            cache[i].last_use = ++use_clock;
+            found = cache[i].plan;
+            break;
+        }
+        if (!cache[i].plan) victim = i;
+        else if (cache[victim].plan && cache[i].last_use < cache[victim].last_use) victim = i;
+    }
+    if (!found) {
+        asx_plan *fresh = asx_plan_create(sample_len, 1, -1);
+        if (fresh) {
+            if (cache[victim].plan) asx_plan_destroy(cache[victim].plan);
+            cache[victim].plan = fresh;
+            cache[victim].sample_len = sample_len;
+            cache[victim].last_use = ++use_clock;
+            found = fresh;
+        }
+    }
+    pthread_mutex_unlock(&cache_mutex);
+    return found;
+}
+
+/* Drops every cached plan (frees the HBM workspaces).  Safe to call any time no
+ * cross_correlation() is in flight. */
+void audiosync_release_plans(void)
+{
+    pthread_mutex_lock(&cache_mutex);
+    for (int i = 0; i < PLAN_CACHE_SLOTS; i++) {
+        if (cache[i].plan) asx_plan_destroy(cache[i].plan);
+        cache[i].plan = NULL;
+    }
+    pthread_mutex_unlock(&cache_mutex);
+}
+
+int cross_correlation(double *source, double *sample, const size_t sample_len, long *lag,
+                      double *coefficient)
+{
+    DEBUG_ASSERT(source); DEBUG_ASSERT(sample);
+    DEBUG_ASSERT(lag); DEBUG_ASSERT(coefficient);
+    DEBUG_ASSERT(sample_len > 0);
+
+    asx_plan *plan = plan_for(sample_len);
+    if (plan == NULL) {
+        /* same class of failure as a failed fftw_alloc_* in the reference: -1, outputs untouched */
+        fprintf(stderr, "audiosync: no GPU plan for %zu frames: %s\n", sample_len, asx_last_error());
+        return -1;
+    }
+    const int ret = asx_xcorr_f64(plan, source, sample, lag, coefficient);
+    if (ret == 0) {
+        LOG("%ld frames of delay with a confidence of %f", *lag, *coefficient);
+    }
+    return ret;
+}
+
+double pearson_coefficient(double *source_start, const double *source_end, double *sample_start,
+                           const double *sample_end)
+{
+    DEBUG_ASSERT(source_start); DEBUG_ASSERT(source_end);
+    DEBUG_ASSERT(source_end - source_start > 0);
+    DEBUG_ASSERT(sample_start); DEBUG_ASSERT(sample_end);
+    DEBUG_ASSERT(sample_end - sample_start > 0);
+    UNUSED(sample_end);
+
+    double value = NAN;
+    const size_t n = (size_t)(source_end - source_start);
+    if (asx_pearson_f64(source_start, sample_start, n, -1, &value) != 0) {
+        fprintf(stderr, "audiosync: pearson_coefficient failed on the GPU: %s\n", asx_last_error());
+        return NAN;
+    }
+    return value;
+}

@@ -161,3 +161,74 @@ def reference_r(source, sample):
     t = np.zeros(2 * N); t[:N] = sample
     X = np.fft.rfft(np.asarray(source, dtype=float)); Y = np.fft.rfft(t)
     return np.fft.irfft(X * np.conj(Y), 2 * N) * (2 * N)
+
+
+# ---------------------------------------------------------------------------
+# In-place DIF / DIT stage model (what csrc/lds_fft.hip does inside LDS).
+#   forward : natural order in  -> digit-reversed out   (Gentleman-Sande, DIF)
+#   inverse : digit-reversed in -> natural order out    (Cooley-Tukey,   DIT)
+# radices R_0..R_{s-1};  stage i works on sub-blocks of length ns_i = n / (R_0..R_{i-1})
+# ---------------------------------------------------------------------------
+
+def radix_list(n):
+    out = []
+    for r in (4, 2, 3, 5):
+        while n % r == 0:
+            out.append(r)
+            n //= r
+    assert n == 1, "length must be {2,3,5}-smooth"
+    return out
+
+
+def dif_forward_inplace(x, radices):
+    x = np.array(x, dtype=complex)
+    n = x.size
+    ns = n
+    for R in radices:
+        q = ns // R
+        y = x.copy()
+        for b in range(n // ns):
+            for j in range(q):
+                v = np.array([x[b * ns + j + t * q] for t in range(R)])
+                out = np.fft.fft(v)  # DFT_R
+                for u in range(R):
+                    y[b * ns + j + u * q] = out[u] * tw(ns, j * u)
+        x = y
+        ns = q
+    return x
+
+
+def dit_inverse_inplace(x, radices):
+    x = np.array(x, dtype=complex)
+    n = x.size
+    # stage i of the forward run used ns_i; run them backwards
+    ns_list = []
+    ns = n
+    for R in radices:
+        ns_list.append(ns)
+        ns //= R
+    for R, ns in reversed(list(zip(radices, ns_list))):
+        q = ns // R
+        y = x.copy()
+        for b in range(n // ns):
+            for j in range(q):
+                v = np.array([x[b * ns + j + u * q] * np.conj(tw(ns, j * u)) for u in range(R)])
+                out = np.fft.ifft(v) * R
+                for t in range(R):
+                    y[b * ns + j + t * q] = out[t]
+        x = y
+    return x
+
+
+def position_table(n, radices):
+    """pos[k] = slot holding X[k] after dif_forward_inplace.
+    k = u0 + R0*u1 + R0*R1*u2 + ... ;  pos = u0*(n/R0) + u1*(n/(R0*R1)) + ... """
+    pos = np.zeros(n, dtype=np.int64)
+    for k in range(n):
+        rem, p, stride = k, 0, n
+        for R in radices:
+            stride //= R
+            p += (rem % R) * stride
+            rem //= R
+        pos[k] = p
+    return pos

@@ -1,0 +1,85 @@
+"""Host planning arithmetic (csrc/plan_math.cpp) against the NumPy model of the device
+algorithm (tests/model_fourstep.py): transform length, split, radix schedule, digit-reversal
+tables, twiddle tables.  No GPU needed."""
+import numpy as np
+import pytest
+
+import model_fourstep as model
+from util import asx
+
+PRODUCTION = [144000, 288000, 480000, 720000, 960000, 1440000]
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 6, 7, 11, 13, 100, 1000, 1001, 4096, 48000, 12345] + PRODUCTION)
+def test_length_and_split(n):
+    d = asx().planmath_describe(n)
+    F, valid = model.embed_params(n, model.next_smooth_even)
+    assert d["F"] == F and d["src_valid"] == valid
+    M = F // 2
+    assert d["M1"] * d["M2"] == M
+    assert d["T"] >= 1 and d["T"] & (d["T"] - 1) == 0 and d["T"] <= 64
+    assert d["M1"] * d["T"] * 8 <= 64 * 1024 and 4 * d["M2"] * 8 <= 64 * 1024
+    assert int(np.prod(d["radix1"], dtype=np.int64)) == d["M1"]
+    assert int(np.prod(d["radix2"], dtype=np.int64)) == d["M2"]
+    assert set(d["radix1"] + d["radix2"]) <= {2, 3, 4, 5}
+
+
+@pytest.mark.parametrize("n", PRODUCTION)
+def test_production_lengths_are_not_embedded_and_use_wide_tiles(n):
+    d = asx().planmath_describe(n)
+    assert d["F"] == 2 * n          # true circular correlation of length 2N
+    assert d["T"] >= 8              # at least 64-byte row segments in the column kernels
+
+
+@pytest.mark.parametrize("n", [6, 30, 1000, 48000, 144000])
+def test_position_tables_match_model(n):
+    mod = asx()
+    d = mod.planmath_describe(n)
+    pos1 = mod.planmath_table(n, 0)
+    inv1 = mod.planmath_table(n, 1)
+    pos2 = mod.planmath_table(n, 2)
+    assert np.array_equal(pos1, model.position_table(d["M1"], d["radix1"]))
+    assert np.array_equal(pos2, model.position_table(d["M2"], d["radix2"]))
+    assert np.array_equal(inv1[pos1], np.arange(d["M1"]))
+    assert sorted(pos2.tolist()) == list(range(d["M2"]))
+
+
+def test_split_override_and_rejects():
+    mod = asx()
+    d = mod.planmath_describe(1000, "25x40x8")
+    assert (d["M1"], d["M2"], d["T"]) == (25, 40, 8)
+    for bad in ("25x41x8", "25x40x3", "0x1000x8", "nonsense"):
+        with pytest.raises(mod.AsxError):
+            mod.planmath_describe(1000, bad)
+
+
+@pytest.mark.parametrize("n", [1000, 144000, 1440000])
+def test_twiddle_tables(n):
+    mod = asx()
+    d = mod.planmath_describe(n)
+    F, M1, M2 = d["F"], d["M1"], d["M2"]
+    tw1 = mod.planmath_twiddles(n, 0)
+    tw2 = mod.planmath_twiddles(n, 1)
+    lo = mod.planmath_twiddles(n, 2)
+    hi = mod.planmath_twiddles(n, 3)
+    twb = mod.planmath_twiddles(n, 4)
+    assert np.abs(tw1 - model.tw(M1, np.arange(M1))).max() < 1e-7
+    assert np.abs(tw2 - model.tw(M2, np.arange(M2))).max() < 1e-7
+    assert np.abs(twb - model.tw(F, M1 * np.arange(M2))).max() < 1e-7
+    # the two-level table reproduces w_F^p for random p < F to float32 accuracy
+    rng = np.random.default_rng(0)
+    p = rng.integers(0, F, 4096)
+    got = lo[p & 2047].astype(np.complex128) * hi[p >> 11].astype(np.complex128)
+    assert np.abs(got - model.tw(F, p)).max() < 2.5e-7
+
+
+def test_inplace_stage_model_round_trip():
+    # the in-place DIF / DIT recipe the kernels use (lds_fft.h), checked in float64
+    rng = np.random.default_rng(3)
+    for n in (1, 2, 5, 12, 60, 360):
+        rad = model.radix_list(n)
+        x = rng.normal(size=n) + 1j * rng.normal(size=n)
+        y = model.dif_forward_inplace(x, rad)
+        pos = model.position_table(n, rad)
+        assert np.abs(y[pos] - np.fft.fft(x)).max() < 1e-10
+        assert np.abs(model.dit_inverse_inplace(y, rad) - n * x).max() < 1e-9
