@@ -74,7 +74,7 @@ struct asx_plan {
     std::vector<void *> allocs; // everything to hipFree on destroy
     // workspaces for one group
     float2 *zxa = nullptr, *zya = nullptr, *ga = nullptr;
-    asx_peak_t *partials = nullptr;
+    AsxPeakWs pk{};
     AsxSeg *seg = nullptr;
     double *psums = nullptr;
     // staging for the host-pointer entry points (lazy)
@@ -141,7 +141,10 @@ static int plan_init(asx_plan *p, size_t N, size_t max_batch, const char *split)
     if (g > max_batch) g = max_batch;
     p->group = g;
     if (dev_alloc(p, &p->zxa, g * h.M) || dev_alloc(p, &p->zya, g * h.M) || dev_alloc(p, &p->ga, g * h.M) ||
-        dev_alloc(p, &p->partials, g * (size_t)h.ntiles) || dev_alloc(p, &p->seg, g) ||
+        dev_alloc(p, &p->pk.partials, g * (size_t)h.ntiles) || dev_alloc(p, &p->pk.cand_n, g * (size_t)h.ntiles) ||
+        dev_alloc(p, &p->pk.cand, g * (size_t)h.ntiles * ASX_CAND_TILE) || dev_alloc(p, &p->pk.refine_n, g) ||
+        dev_alloc(p, &p->pk.refine_idx, g * ASX_CAND_PAIR) || dev_alloc(p, &p->pk.refine_val, g * ASX_CAND_PAIR) ||
+        dev_alloc(p, &p->seg, g) ||
         dev_alloc(p, &p->psums, g * ASX_PEARSON_BLOCKS * 5))
         return -1;
     HIP_TRY(hipStreamCreate(&p->stream));
@@ -245,9 +248,13 @@ static int run_group(asx_plan *p, const float *d_src, const float *d_smp, const 
     if (prof_mark(p, s, e0 + 1)) return -1;
     asx_launch_rows(P, p->zxa, p->zya, p->ga, (int)g, s);
     if (prof_mark(p, s, e0 + 2)) return -1;
-    asx_launch_inv_cols(P, p->ga, p->partials, d_r, (int)g, s);
+    asx_launch_inv_cols(P, p->ga, p->pk, d_r, (int)g, s);
     if (prof_mark(p, s, e0 + 3)) return -1;
-    asx_launch_finalize(P, p->partials, p->seg, (int)g, s);
+    asx_launch_finalize(P, p->pk, p->seg, (int)g, s);
+    if (sizeof(TIn) == sizeof(float))
+        asx_launch_refine_f32(P, (const float *)p_src, (const float *)p_smp, p->pk, p->seg, (int)g, s);
+    else
+        asx_launch_refine_f64(P, (const double *)p_src, (const double *)p_smp, p->pk, p->seg, (int)g, s);
     if (prof_mark(p, s, e0 + 4)) return -1;
     if (sizeof(TIn) == sizeof(float))
         asx_launch_pearson_f32((const float *)p_src, (const float *)p_smp, 2 * (size_t)P.N, P.N, P.N,

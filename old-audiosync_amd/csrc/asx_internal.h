@@ -18,6 +18,13 @@
 #define ASX_TW_LO (1u << ASX_TW_LOG)
 #define ASX_THREADS 256                     // block size of every kernel here
 #define ASX_PEARSON_BLOCKS 64               // partial-sum blocks per pair
+// Peak refinement: every lag whose float32 |r| is within ASX_REFINE_EPS (relative) of the
+// float32 maximum is re-evaluated exactly (float64 dot product of the inputs) and the
+// reference's rule is applied to the exact values, so near-ties that float32 transforms
+// cannot resolve (e.g. the reference's own sin(i) test, margin 3e-8) come out as in float64.
+#define ASX_REFINE_EPS 1.0e-4f
+#define ASX_CAND_TILE 8                     // candidates kept per column tile
+#define ASX_CAND_PAIR 32                    // candidates re-evaluated per pair (more -> float32 result kept)
 
 // Radix schedule of one in-LDS transform of length n.
 // DIF stage i works on sub-blocks of length ns[i] = n / (radix[0]*...*radix[i-1]).
@@ -72,10 +79,28 @@ void asx_launch_fwd_cols(const AsxDev &P, const float *src, const float *smp, fl
                          float2 *zya, int npairs, hipStream_t s);
 void asx_launch_rows(const AsxDev &P, const float2 *zxa, const float2 *zya, float2 *ga, int npairs,
                      hipStream_t s);
-void asx_launch_inv_cols(const AsxDev &P, const float2 *ga, asx_peak_t *partials, float *r_out,
+struct AsxCand {          // one near-maximum lag found by a column tile
+    uint32_t idx;
+    float key;
+};
+
+// per-group scratch of the peak search
+struct AsxPeakWs {
+    asx_peak_t *partials;  // [pairs][ntiles] tile maxima
+    uint32_t *cand_n;      // [pairs][ntiles] candidates seen by the tile (may exceed ASX_CAND_TILE)
+    AsxCand *cand;         // [pairs][ntiles][ASX_CAND_TILE]
+    uint32_t *refine_n;    // [pairs] lags to re-evaluate (0 = keep the float32 argmax)
+    uint32_t *refine_idx;  // [pairs][ASX_CAND_PAIR]
+    double *refine_val;    // [pairs][ASX_CAND_PAIR] exact r[idx]
+};
+
+void asx_launch_inv_cols(const AsxDev &P, const float2 *ga, const AsxPeakWs &W, float *r_out,
                          int npairs, hipStream_t s);
-void asx_launch_finalize(const AsxDev &P, const asx_peak_t *partials, AsxSeg *seg, int npairs,
-                         hipStream_t s);
+void asx_launch_finalize(const AsxDev &P, const AsxPeakWs &W, AsxSeg *seg, int npairs, hipStream_t s);
+void asx_launch_refine_f32(const AsxDev &P, const float *src, const float *smp, const AsxPeakWs &W,
+                           AsxSeg *seg, int npairs, hipStream_t s);
+void asx_launch_refine_f64(const AsxDev &P, const double *src, const double *smp, const AsxPeakWs &W,
+                           AsxSeg *seg, int npairs, hipStream_t s);
 void asx_launch_pearson_f32(const float *src, const float *smp, size_t src_pitch, size_t smp_pitch,
                             uint32_t basis_len, const AsxSeg *seg, double *psums, int64_t *lag,
                             double *coef, int32_t *ret, int npairs, hipStream_t s);

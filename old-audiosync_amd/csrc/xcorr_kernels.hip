@@ -187,6 +187,13 @@ __global__ __launch_bounds__(ASX_THREADS) void k_rows(AsxDev P, const float2 *__
     }
 }
 
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
 // ---------------------------------------------------------------------------
 // peak search helpers (src/cross_correlation.c:52-67)
 // ---------------------------------------------------------------------------
@@ -235,11 +242,26 @@ __device__ __forceinline__ asx_peak_t block_peak_max(asx_peak_t v, asx_peak_t *s
 // k_inv_cols: grid (ntiles, npairs).  Inverse column transforms; the time-domain
 // correlation r[2j] = Re g[j], r[2j+1] = Im g[j] only lives in LDS/registers.
 // ---------------------------------------------------------------------------
+__device__ __forceinline__ float peak_key(asx_peak_t v)
+{
+    uint32_t b = (uint32_t)(v >> 32);
+    b = (b & 0x80000000u) ? (b & 0x7FFFFFFFu) : ~b;
+    return __uint_as_float(b);
+}
+__device__ __forceinline__ uint32_t peak_index(asx_peak_t v) { return 0xFFFFFFFFu - (uint32_t)(v & 0xFFFFFFFFull); }
+// everything at or above this key is "as large as the maximum" for float32 transforms
+__device__ __forceinline__ float near_max_threshold(float kmax)
+{
+    return kmax > 0.f ? kmax * (1.0f - ASX_REFINE_EPS) : kmax;
+}
+
 __global__ __launch_bounds__(ASX_THREADS) void k_inv_cols(AsxDev P, const float2 *__restrict__ ga,
-                                                           asx_peak_t *__restrict__ partials,
-                                                           float *__restrict__ r_out)
+                                                           AsxPeakWs W, float *__restrict__ r_out)
 {
     __shared__ asx_peak_t red[ASX_THREADS / 64];
+    __shared__ asx_peak_t tile_best;
+    __shared__ uint32_t ncand;
+    __shared__ AsxCand lcand[ASX_CAND_TILE];
     const int tile = blockIdx.x;
     const size_t pair = blockIdx.y;
     const int T = P.T, logT = P.logT, M1 = P.M1, M2 = P.M2;
@@ -252,6 +274,7 @@ __global__ __launch_bounds__(ASX_THREADS) void k_inv_cols(AsxDev P, const float2
         const int j2 = c0 + c;
         asx_lds[e] = (j2 < M2) ? in[(size_t)p1 * M2 + j2] : make_float2(0.f, 0.f);
     }
+    if (threadIdx.x == 0) ncand = 0;
     __syncthreads();
     lds_fft<true, true>(asx_lds, P.st1, T, logT, T, 1, P.tw1);
 
@@ -273,42 +296,158 @@ __global__ __launch_bounds__(ASX_THREADS) void k_inv_cols(AsxDev P, const float2
         }
     }
     best = block_peak_max(best, red);
-    if (threadIdx.x == 0) partials[pair * (size_t)P.ntiles + tile] = best;
+    if (threadIdx.x == 0) tile_best = best;
+    __syncthreads();
+
+    // second look at the tile (still in LDS): lags as large as the tile maximum within
+    // float32 accuracy.  A lag near the GLOBAL maximum is necessarily near its tile's maximum.
+    const float thr = near_max_threshold(peak_key(tile_best));
+    for (int e = threadIdx.x; e < nelem; e += ASX_THREADS) {
+        const int c = e & (T - 1), j1 = e >> logT;
+        const int j2 = c0 + c;
+        if (j2 < M2) {
+            const uint32_t i0 = 2u * ((uint32_t)j1 * (uint32_t)M2 + (uint32_t)j2);
+            const float2 g = asx_lds[e];
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const uint32_t idx = i0 + h;
+                if (idx < P.nout) {
+                    const float key = peak_key(peak_pack(h ? g.y : g.x, idx));
+                    if (key >= thr) {
+                        const uint32_t slot = atomicAdd(&ncand, 1u);
+                        if (slot < ASX_CAND_TILE) { lcand[slot].idx = idx; lcand[slot].key = key; }
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const size_t t = pair * (size_t)P.ntiles + tile;
+    if (threadIdx.x == 0) {
+        W.partials[t] = tile_best;
+        W.cand_n[t] = ncand;
+    }
+    if (threadIdx.x < ASX_CAND_TILE && threadIdx.x < ncand) W.cand[t * ASX_CAND_TILE + threadIdx.x] = lcand[threadIdx.x];
 }
 
 // ---------------------------------------------------------------------------
 // k_finalize: grid (npairs).  Reduce tile partials, wrap the lag, pick segments.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(ASX_THREADS) void k_finalize(AsxDev P, const asx_peak_t *__restrict__ partials,
-                                                           AsxSeg *__restrict__ seg)
+__device__ __forceinline__ AsxSeg make_seg(uint32_t peak, uint32_t N)
+{
+    AsxSeg s;
+    s.peak = peak;
+    if (peak >= N) {
+        // src/cross_correlation.c:256-263: lag = (lag % N) - N; source[0 .. N+lag), sample[-lag .. N)
+        const long long l = (long long)(peak % N) - (long long)N;
+        s.lag = l;
+        s.src_off = 0;
+        s.smp_off = (uint32_t)(-l);
+        s.len = (uint32_t)((long long)N + l);
+    } else {
+        // :264-271: source[lag .. lag+N), sample[0 .. N)
+        s.lag = (long long)peak;
+        s.src_off = peak;
+        s.smp_off = 0;
+        s.len = N;
+    }
+    return s;
+}
+
+__global__ __launch_bounds__(ASX_THREADS) void k_finalize(AsxDev P, AsxPeakWs W, AsxSeg *__restrict__ seg)
 {
     __shared__ asx_peak_t red[ASX_THREADS / 64];
+    __shared__ asx_peak_t pair_best;
+    __shared__ uint32_t nsel, overflow;
+    __shared__ uint32_t sel[ASX_CAND_PAIR];
     const size_t pair = blockIdx.x;
+    const asx_peak_t *partials = W.partials + pair * (size_t)P.ntiles;
     asx_peak_t best = 0;
-    for (int t = threadIdx.x; t < P.ntiles; t += ASX_THREADS)
-        best = peak_max(best, partials[pair * (size_t)P.ntiles + t]);
+    for (int t = threadIdx.x; t < P.ntiles; t += ASX_THREADS) best = peak_max(best, partials[t]);
     best = block_peak_max(best, red);
-    if (threadIdx.x == 0) {
-        const uint32_t peak = 0xFFFFFFFFu - (uint32_t)(best & 0xFFFFFFFFull);
-        const uint32_t N = P.N;
-        AsxSeg s;
-        s.peak = peak;
-        if (peak >= N) {
-            // src/cross_correlation.c:256-263: lag = (lag % N) - N; source[0 .. N+lag), sample[-lag .. N)
-            const long long l = (long long)(peak % N) - (long long)N;
-            s.lag = l;
-            s.src_off = 0;
-            s.smp_off = (uint32_t)(-l);
-            s.len = (uint32_t)((long long)N + l);
-        } else {
-            // :264-271: source[lag .. lag+N), sample[0 .. N)
-            s.lag = (long long)peak;
-            s.src_off = peak;
-            s.smp_off = 0;
-            s.len = N;
+    if (threadIdx.x == 0) { pair_best = best; nsel = 0; overflow = 0; }
+    __syncthreads();
+
+    // gather the tiles' near-maximum lags that are also near the pair's maximum
+    const float thr = near_max_threshold(peak_key(pair_best));
+    for (int t = threadIdx.x; t < P.ntiles; t += ASX_THREADS) {
+        if (peak_key(partials[t]) < thr) continue;        // nothing in this tile can matter
+        const size_t tt = pair * (size_t)P.ntiles + t;
+        const uint32_t n = W.cand_n[tt];
+        if (n > ASX_CAND_TILE) atomicOr(&overflow, 1u);
+        for (uint32_t i = 0; i < n && i < ASX_CAND_TILE; i++) {
+            const AsxCand c = W.cand[tt * ASX_CAND_TILE + i];
+            if (c.key >= thr) {
+                const uint32_t slot = atomicAdd(&nsel, 1u);
+                if (slot < ASX_CAND_PAIR) sel[slot] = c.idx;
+            }
         }
-        seg[pair] = s;
     }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        seg[pair] = make_seg(peak_index(pair_best), P.N);
+        // one candidate: the float32 argmax is unambiguous.  Too many (e.g. r == 0 everywhere):
+        // keep the float32 result, which already follows the smallest-index rule.
+        const bool refine = (nsel >= 2u && nsel <= ASX_CAND_PAIR && !overflow);
+        W.refine_n[pair] = refine ? nsel : 0u;
+    }
+    if (threadIdx.x < ASX_CAND_PAIR && threadIdx.x < nsel) W.refine_idx[pair * ASX_CAND_PAIR + threadIdx.x] = sel[threadIdx.x];
+}
+
+// ---------------------------------------------------------------------------
+// Exact re-evaluation of near-tied lags: r[k] = sum_{n<N} source[(n+k) mod 2N] * sample[n]
+// (the identity behind src/cross_correlation.c:232-239) in float64.
+// grid (ASX_CAND_PAIR, npairs); blocks beyond refine_n exit at once.
+// ---------------------------------------------------------------------------
+
+template <typename TIn>
+__global__ __launch_bounds__(ASX_THREADS) void k_refine_dots(AsxDev P, const TIn *__restrict__ src,
+                                                              const TIn *__restrict__ smp, AsxPeakWs W)
+{
+    __shared__ double red[ASX_THREADS / 64];
+    const size_t pair = blockIdx.y;
+    if (blockIdx.x >= W.refine_n[pair]) return;
+    const uint32_t k = W.refine_idx[pair * ASX_CAND_PAIR + blockIdx.x];
+    const uint32_t N = P.N, L = 2u * P.N;
+    const TIn *x = src + pair * (size_t)L;
+    const TIn *y = smp + pair * (size_t)N;
+    double acc = 0.0;
+    for (uint32_t n = threadIdx.x; n < N; n += ASX_THREADS) {
+        uint32_t i = n + k;
+        if (i >= L) i -= L;
+        acc += (double)x[i] * (double)y[n];
+    }
+    acc = wave_sum(acc);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) red[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = red[0];
+        for (int w = 1; w < ASX_THREADS / 64; w++) t += red[w];
+        W.refine_val[pair * ASX_CAND_PAIR + blockIdx.x] = t;
+    }
+}
+
+// grid (npairs), one thread decides: the reference's max_abs_index rule on the exact values
+__global__ __launch_bounds__(64) void k_refine_pick(AsxDev P, AsxPeakWs W, AsxSeg *__restrict__ seg)
+{
+    const size_t pair = blockIdx.x;
+    const uint32_t n = W.refine_n[pair];
+    if (n < 2u || threadIdx.x != 0) return;
+    double best_key = 0.0;
+    uint32_t best_idx = 0xFFFFFFFFu;
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t idx = W.refine_idx[pair * ASX_CAND_PAIR + i];
+        const double v = W.refine_val[pair * ASX_CAND_PAIR + i];
+        double key;
+        if (idx == 0u) key = (v != v) ? INFINITY : v + 0.0;
+        else { key = fabs(v); if (key != key) key = -INFINITY; }
+        if (best_idx == 0xFFFFFFFFu || key > best_key || (key == best_key && idx < best_idx)) {
+            best_key = key;
+            best_idx = idx;
+        }
+    }
+    seg[pair] = make_seg(best_idx, P.N);
 }
 
 // ---------------------------------------------------------------------------
@@ -317,12 +456,6 @@ __global__ __launch_bounds__(ASX_THREADS) void k_finalize(AsxDev P, const asx_pe
 // (block-partition by index, wave butterflies), so identical segments give
 // bit-identical Sxx, Syy, Sxy and therefore exactly +-1.0.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ double wave_sum(double v)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
 
 template <typename TIn>
 __global__ __launch_bounds__(ASX_THREADS) void k_pearson_partial(const TIn *__restrict__ src,
@@ -468,17 +601,30 @@ void asx_launch_rows(const AsxDev &P, const float2 *zxa, const float2 *zya, floa
     hipLaunchKernelGGL(k_rows, grid, dim3(ASX_THREADS), asx_lds_bytes_rows(P), s, P, zxa, zya, ga);
 }
 
-void asx_launch_inv_cols(const AsxDev &P, const float2 *ga, asx_peak_t *partials, float *r_out,
-                         int npairs, hipStream_t s)
-{
-    dim3 grid(P.ntiles, npairs);
-    hipLaunchKernelGGL(k_inv_cols, grid, dim3(ASX_THREADS), asx_lds_bytes_cols(P), s, P, ga, partials, r_out);
-}
-
-void asx_launch_finalize(const AsxDev &P, const asx_peak_t *partials, AsxSeg *seg, int npairs,
+void asx_launch_inv_cols(const AsxDev &P, const float2 *ga, const AsxPeakWs &W, float *r_out, int npairs,
                          hipStream_t s)
 {
-    hipLaunchKernelGGL(k_finalize, dim3(npairs), dim3(ASX_THREADS), 0, s, P, partials, seg);
+    dim3 grid(P.ntiles, npairs);
+    hipLaunchKernelGGL(k_inv_cols, grid, dim3(ASX_THREADS), asx_lds_bytes_cols(P), s, P, ga, W, r_out);
+}
+
+void asx_launch_finalize(const AsxDev &P, const AsxPeakWs &W, AsxSeg *seg, int npairs, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_finalize, dim3(npairs), dim3(ASX_THREADS), 0, s, P, W, seg);
+}
+
+void asx_launch_refine_f32(const AsxDev &P, const float *src, const float *smp, const AsxPeakWs &W,
+                           AsxSeg *seg, int npairs, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_refine_dots<float>, dim3(ASX_CAND_PAIR, npairs), dim3(ASX_THREADS), 0, s, P, src, smp, W);
+    hipLaunchKernelGGL(k_refine_pick, dim3(npairs), dim3(64), 0, s, P, W, seg);
+}
+
+void asx_launch_refine_f64(const AsxDev &P, const double *src, const double *smp, const AsxPeakWs &W,
+                           AsxSeg *seg, int npairs, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_refine_dots<double>, dim3(ASX_CAND_PAIR, npairs), dim3(ASX_THREADS), 0, s, P, src, smp, W);
+    hipLaunchKernelGGL(k_refine_pick, dim3(npairs), dim3(64), 0, s, P, W, seg);
 }
 
 void asx_launch_pearson_f32(const float *src, const float *smp, size_t src_pitch, size_t smp_pitch,

@@ -1,6 +1,7 @@
 """ctypes view of libaudiosync_hip.so (the C-ABI in include/audiosync/xcorr_hip.h)."""
 import ctypes
 import os
+import sys
 
 import numpy as np
 
@@ -29,6 +30,20 @@ class AsxError(RuntimeError):
     pass
 
 
+def _one_hip_runtime():
+    """PyTorch's ROCm wheel ships its own libamdhip64.so (same SONAME as /opt/rocm's).  Two HIP
+    runtimes in one process do not work, so when torch is installed it is imported FIRST: the
+    loader then binds this library's libamdhip64.so.7 dependency to the copy torch already
+    loaded, and torch tensors / streams can be handed to the C-ABI as raw pointers.
+    ASX_NO_TORCH=1 skips this (pure C / ctypes users of the system runtime)."""
+    if os.environ.get("ASX_NO_TORCH") == "1" or "torch" in sys.modules:
+        return
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+
+
 def lib():
     """dlopen the HIP layer; raises if it has not been built (no fallback)."""
     global _lib
@@ -37,6 +52,7 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise AsxError(LIB_PATH + " is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                        "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    _one_hip_runtime()
     L = ctypes.CDLL(LIB_PATH)
     vp = ctypes.c_void_p
     L.asx_device_count.restype = ctypes.c_int
