@@ -170,7 +170,7 @@ def main():
             "config": {"workload": "batched xcorr, N=%d frames/sample (source 2N), %d pairs per GPU per step, "
                                    "48 kHz mono float32, planted delays, SNR 0 dB" % (n, batch),
                        "sample_len": n, "pairs_per_gpu": batch, "group": plan.group,
-                       "split": "%dx%dx%d" % (m1, m2, tcols), "parallelism": "pairs sharded over %d GPU(s), RCCL all_gather of results" % world},
+                       "split": "%dx%dx%d" % (m1, m2, tcols), "threads_cols_rows": list(plan.threads), "parallelism": "pairs sharded over %d GPU(s), RCCL all_gather of results" % world},
             "results_ok": ok,
             "roofline": roofline,
         }

@@ -69,6 +69,7 @@ void asx_plan_destroy(asx_plan *plan);
 size_t asx_plan_sample_len(const asx_plan *plan);
 size_t asx_plan_fft_len(const asx_plan *plan);        /* F, real transform length */
 int asx_plan_split(const asx_plan *plan, int *m1, int *m2, int *tile_cols);
+int asx_plan_threads(const asx_plan *plan, int *threads_cols, int *threads_rows); /* block sizes */
 size_t asx_plan_group(const asx_plan *plan);          /* pairs per launch group */
 size_t asx_plan_workspace_bytes(const asx_plan *plan);
 

@@ -123,6 +123,10 @@ static int plan_init(asx_plan *p, size_t N, size_t max_batch, const char *split)
     d.src_period = (uint32_t)(2 * N);
     d.nout = (uint32_t)(2 * N);
     d.st1 = h.st1; d.st2 = h.st2;
+    d.threads_cols = asx_pick_threads(h.st1, h.T / 2, 64, asx_lds_bytes_cols(d));
+    d.threads_rows = asx_pick_threads(h.st2, 2, (h.M2 + ASX_ROW_STEPS - 1) / ASX_ROW_STEPS, asx_lds_bytes_rows(d));
+    if (const char *e = getenv("ASX_THREADS_COLS")) d.threads_cols = atoi(e);
+    if (const char *e = getenv("ASX_THREADS_ROWS")) d.threads_rows = atoi(e);
     if (dev_upload(p, &d.tw1, h.tw1) || dev_upload(p, &d.tw2, h.tw2) || dev_upload(p, &d.tw_lo, h.tw_lo) ||
         dev_upload(p, &d.tw_hi, h.tw_hi) || dev_upload(p, &d.tw_b, h.tw_b) ||
         dev_upload(p, &d.k1_of_pos1, h.k1_of_pos1) || dev_upload(p, &d.pos1_of_k1, h.pos1_of_k1) ||
@@ -131,7 +135,7 @@ static int plan_init(asx_plan *p, size_t N, size_t max_batch, const char *split)
 
     // group size: keep the three inter-kernel intermediates (24*M bytes per pair) of one
     // group around the size of the 256 MiB Infinity Cache so the next kernel re-reads them on die
-    size_t ws_mb = 160;
+    size_t ws_mb = 1024;
     if (const char *e = getenv("ASX_WS_MB")) ws_mb = (size_t)atol(e) > 0 ? (size_t)atol(e) : ws_mb;
     size_t per_pair = (size_t)3 * h.M * sizeof(float2);
     size_t g = (ws_mb << 20) / per_pair;
@@ -147,6 +151,12 @@ static int plan_init(asx_plan *p, size_t N, size_t max_batch, const char *split)
         dev_alloc(p, &p->seg, g) ||
         dev_alloc(p, &p->psums, g * ASX_PEARSON_BLOCKS * 5))
         return -1;
+    {
+        AsxDev *dcopy = nullptr;
+        if (dev_alloc(p, &dcopy, 1)) return -1;
+        d.self_dev = dcopy;
+        HIP_TRY(hipMemcpy(dcopy, &d, sizeof(AsxDev), hipMemcpyHostToDevice));
+    }
     HIP_TRY(hipStreamCreate(&p->stream));
     return 0;
 }
@@ -201,6 +211,14 @@ extern "C" size_t asx_plan_sample_len(const asx_plan *p) { return p ? p->host.N 
 extern "C" size_t asx_plan_fft_len(const asx_plan *p) { return p ? p->host.F : 0; }
 extern "C" size_t asx_plan_group(const asx_plan *p) { return p ? p->group : 0; }
 extern "C" size_t asx_plan_workspace_bytes(const asx_plan *p) { return p ? p->ws_bytes : 0; }
+extern "C" int asx_plan_threads(const asx_plan *p, int *cols, int *rows)
+{
+    if (!p) return -1;
+    if (cols) *cols = p->dev.threads_cols;
+    if (rows) *rows = p->dev.threads_rows;
+    return 0;
+}
+
 extern "C" int asx_plan_split(const asx_plan *p, int *m1, int *m2, int *tile_cols)
 {
     if (!p) return -1;

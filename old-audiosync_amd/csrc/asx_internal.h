@@ -16,7 +16,9 @@
 #define ASX_MAX_STAGES 12
 #define ASX_TW_LOG 11                       // two-level twiddle: low table has 2^11 entries
 #define ASX_TW_LO (1u << ASX_TW_LOG)
-#define ASX_THREADS 256                     // block size of every kernel here
+#define ASX_THREADS 256                     // block size of the streaming kernels
+#define ASX_FFT_THREADS_MAX 512             // upper bound for the three transform kernels
+#define ASX_ROW_STEPS 32                    // max ceil(M2 / blockDim) in k_rows
 #define ASX_PEARSON_BLOCKS 64               // partial-sum blocks per pair
 // Peak refinement: every lag whose float32 |r| is within ASX_REFINE_EPS (relative) of the
 // float32 maximum is re-evaluated exactly (float64 dot product of the inputs) and the
@@ -40,13 +42,16 @@ struct AsxStages {
     float inv_nbf[ASX_MAX_STAGES];
 };
 
-// Everything a kernel needs to know about a plan; passed by value.
+// Everything a kernel needs to know about a plan.  Kernels get a POINTER to a device copy:
+// passed by value, the dynamically indexed stage arrays made hipcc spill the whole struct to scratch.
+struct AsxDev;
 struct AsxDev {
     uint32_t N;            // sample_len
     uint32_t F, M;         // real / complex transform length
     int M1, M2;            // M = M1*M2
     int T, logT;           // tile width (columns per block) of the column kernels, power of two
     int ntiles;            // ceil(M2 / T)
+    int threads_cols, threads_rows; // block sizes of the column / row kernels
     uint32_t src_valid;    // how many leading real samples of the (periodically extended) source are non-zero
     uint32_t src_period;   // 2N
     uint32_t nout;         // 2N: lags searched
@@ -59,6 +64,7 @@ struct AsxDev {
     const int *k1_of_pos1; // row slot -> k1
     const int *pos1_of_k1; // k1 -> row slot
     const int *pos2_of_k2; // k2 -> slot inside a row after the forward row transform
+    const AsxDev *self_dev; // device copy of this struct (what the kernels read)
 };
 
 // Peak-search partial: order-preserving key in the high word, ~index in the low word,
@@ -110,5 +116,6 @@ void asx_launch_pearson_f64(const double *src, const double *smp, size_t src_pit
 void asx_launch_cvt_f64_f32(const double *in, float *out, size_t n, hipStream_t s);
 void asx_launch_synth(uint64_t seed, uint64_t first_pair, size_t count, uint32_t N,
                       int noise_shift, float *src, float *smp, int64_t *true_lag, hipStream_t s);
+int asx_pick_threads(const AsxStages &st, int groups, int min_threads, size_t lds_bytes);
 size_t asx_lds_bytes_cols(const AsxDev &P);
 size_t asx_lds_bytes_rows(const AsxDev &P);

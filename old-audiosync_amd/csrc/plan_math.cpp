@@ -21,12 +21,47 @@ uint64_t asx_next_smooth_even(uint64_t n)
     return n;
 }
 
+// Radix schedule: the fewest passes over LDS using radices the kernels implement
+// (lds_fft.h), ties broken by the smallest radix sum.  Order: even radices first
+// (largest first), odd radices last -- the innermost stages (small q) then stride
+// LDS by an odd number of elements, which spreads over the banks.
+static const int kRadices[] = { 16, 15, 12, 10, 9, 8, 6, 5, 4, 3, 2 };
+
+static void search_radices(int rem, int depth, int sum, int *cur, int *best, int *best_depth, int *best_sum,
+                           int min_next)
+{
+    if (rem == 1) {
+        if (depth < *best_depth || (depth == *best_depth && sum < *best_sum)) {
+            *best_depth = depth;
+            *best_sum = sum;
+            for (int i = 0; i < depth; i++) best[i] = cur[i];
+        }
+        return;
+    }
+    if (depth + 1 > *best_depth || depth >= ASX_MAX_STAGES) return;
+    for (int R : kRadices) {
+        if (R > min_next || rem % R) continue; // non-increasing: each multiset visited once
+        cur[depth] = R;
+        search_radices(rem / R, depth + 1, sum + R, cur, best, best_depth, best_sum, R);
+    }
+}
+
 bool asx_make_stages(int n, AsxStages *st)
 {
     *st = AsxStages{};
     st->n = n;
-    int rem = n, ns = n, i = 0;
-    auto push = [&](int R) {
+    int cur[ASX_MAX_STAGES], best[ASX_MAX_STAGES];
+    int best_depth = ASX_MAX_STAGES + 1, best_sum = 1 << 30;
+    if (n < 1) return false;
+    search_radices(n, 0, 0, cur, best, &best_depth, &best_sum, 16);
+    if (best_depth > ASX_MAX_STAGES) return false;
+    // even radices (descending) first, then odd (descending)
+    std::vector<int> order;
+    for (int i = 0; i < best_depth; i++) if (best[i] % 2 == 0) order.push_back(best[i]);
+    for (int i = 0; i < best_depth; i++) if (best[i] % 2 != 0) order.push_back(best[i]);
+    int ns = n;
+    for (int i = 0; i < (int)order.size(); i++) {
+        const int R = order[i];
         st->radix[i] = R;
         st->ns[i] = ns;
         st->q[i] = ns / R;
@@ -35,17 +70,9 @@ bool asx_make_stages(int n, AsxStages *st)
         st->inv_q[i] = 1.0f / (float)(ns / R);
         st->inv_nbf[i] = 1.0f / (float)(n / R);
         ns /= R;
-        rem /= R;
-        i++;
-    };
-    for (int R : { 4, 2, 3, 5 }) {
-        while (rem % R == 0) {
-            if (i >= ASX_MAX_STAGES) return false;
-            push(R);
-        }
     }
-    st->nstages = i;
-    return rem == 1;
+    st->nstages = (int)order.size();
+    return true;
 }
 
 std::vector<int> asx_position_table(const AsxStages &st)
@@ -118,24 +145,32 @@ std::string asx_host_plan_build(size_t N, const char *split_override, AsxHostPla
     int M1 = 0, M2 = 0, T = 0;
     if (split_override && *split_override) {
         if (sscanf(split_override, "%dx%dx%d", &M1, &M2, &T) != 3 || M1 < 1 || M2 < 1 ||
-            (uint64_t)M1 * (uint64_t)M2 != M || T < 1 || (T & (T - 1)) || T > 64 ||
+            (uint64_t)M1 * (uint64_t)M2 != M || T < 2 || (T & (T - 1)) || T > 64 ||
             (size_t)M1 * T * sizeof(float2) > ASX_LDS_HW_MAX ||
             (size_t)4 * M2 * sizeof(float2) > ASX_LDS_HW_MAX)
             return "bad ASX_SPLIT override";
     } else {
-        // smallest worst-case LDS footprint, preferring tiles of at least 8 columns
-        // (64-byte row segments) and then wider tiles
-        size_t best_cost = (size_t)-1;
+        // Cost of a split: the larger LDS footprint of the two kernel families (KiB; it bounds
+        // the blocks per CU), 8 per pass over LDS (stage), 20 if any stage needs radix 15/16
+        // (those bodies spill at 128 VGPRs).  Tiles of at least 8 columns (64-byte row
+        // segments in HBM) are preferred; narrower ones only if nothing else fits.
+        double best_cost = 1e30;
         for (int pass = 0; pass < 2 && M1 == 0; pass++) {
-            const int min_T = pass == 0 ? 8 : 1;
+            const int min_T = pass == 0 ? 8 : 2;
             for (uint32_t a = 1; a <= M && a <= 8192u; a++) {
                 if (M % a) continue;
                 const uint32_t b = M / a;
                 if ((int)b > rows_max) continue;
                 int t = tile_for((int)a);
                 if (t < min_T) continue;
-                while (t > 1 && (uint32_t)t > b) t >>= 1; // never wider than the row
-                size_t cost = std::max((size_t)a * t * sizeof(float2), (size_t)4 * b * sizeof(float2));
+                while (t > 2 && (uint32_t)t > b) t >>= 1; // not wider than the row (but always a column pair)
+                AsxStages s1, s2;
+                if (!asx_make_stages((int)a, &s1) || !asx_make_stages((int)b, &s2)) continue;
+                int maxr = 2;
+                for (int i = 0; i < s1.nstages; i++) maxr = std::max(maxr, s1.radix[i]);
+                for (int i = 0; i < s2.nstages; i++) maxr = std::max(maxr, s2.radix[i]);
+                const double lds = (double)std::max((size_t)a * t * sizeof(float2), (size_t)4 * b * sizeof(float2)) / 1024.0;
+                const double cost = lds + 8.0 * (s1.nstages + s2.nstages) + (maxr > 12 ? 20.0 : 0.0);
                 if (cost < best_cost || (cost == best_cost && t > T)) {
                     best_cost = cost;
                     M1 = (int)a; M2 = (int)b; T = t;

@@ -19,7 +19,7 @@ struct AsxHostPlan {
 };
 
 // LDS budgets that bound the split (bytes per workgroup).
-constexpr size_t ASX_LDS_COLS_MAX = 64 * 1024;  // M1 * T * 8
+constexpr size_t ASX_LDS_COLS_MAX = 80 * 1024;  // M1 * T * 8  (two blocks per CU)
 constexpr size_t ASX_LDS_ROWS_MAX = 64 * 1024;  // 4 * M2 * 8
 constexpr size_t ASX_LDS_HW_MAX = 160 * 1024;   // what one gfx950 workgroup may declare (overrides only)
 

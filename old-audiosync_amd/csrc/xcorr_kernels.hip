@@ -30,61 +30,92 @@ __device__ __forceinline__ float2 tw_F(const AsxDev &P, uint32_t p)
 }
 
 // ---------------------------------------------------------------------------
-// k_fwd_cols: grid (ntiles, 2, npairs).  blockIdx.y: 0 = source, 1 = sample.
-// LDS tile: [M1][T] float2 (row pitch T, T a power of two), transform along rows.
+// Column tiles.  A tile is T columns (T even, a power of two) of the [M1][M2] matrix,
+// held in LDS as [M1][T/2] float4 = two adjacent columns per 16-byte slot, so that one
+// thread transforms two columns with shared twiddles and b128 LDS accesses.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(ASX_THREADS) void k_fwd_cols(AsxDev P, const float *__restrict__ src,
-                                                           const float *__restrict__ smp,
-                                                           float2 *__restrict__ zxa,
-                                                           float2 *__restrict__ zya)
+__device__ __forceinline__ LdsLayout col_layout(const AsxDev &P)
 {
+    LdsLayout L;
+    L.ngroups = P.T >> 1;
+    L.log_ngroups = P.logT - 1;
+    L.elem_stride = P.T;
+    L.group_stride = 2;
+    L.member_stride = 1;
+    return L;
+}
+
+// k_fwd_cols: grid (ntiles, 2, npairs).  blockIdx.y: 0 = source, 1 = sample.
+// Packs real samples as complex (z[j] = x[2j] + i x[2j+1]); zero padding and the periodic
+// extension of the source (embedded lengths) happen in the loads, never in HBM.
+template <int MAXR>
+__global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_fwd_cols(const AsxDev *__restrict__ Pp, const float *__restrict__ src,
+                                                                   const float *__restrict__ smp,
+                                                                   float2 *__restrict__ zxa,
+                                                                   float2 *__restrict__ zya)
+{
+    const AsxDev &P = *Pp; // plan constants live in device memory: uniform scalar loads
     const int tile = blockIdx.x;
     const bool is_smp = blockIdx.y != 0;
     const size_t pair = blockIdx.z;
-    const int T = P.T, logT = P.logT, M1 = P.M1, M2 = P.M2;
+    const int T = P.T, logH = P.logT - 1, H = T >> 1, M1 = P.M1, M2 = P.M2;
     const int c0 = tile * T;
 
     const float *in = is_smp ? smp + pair * (size_t)P.N : src + pair * (size_t)P.src_period;
     const uint32_t valid = is_smp ? P.N : P.src_valid;      // real samples that are not zero padding
     const uint32_t period = is_smp ? P.N : P.src_period;    // source may be periodically extended
     float2 *out = (is_smp ? zya : zxa) + pair * (size_t)P.M;
-    const bool vec_ok = ((reinterpret_cast<uintptr_t>(in) & 7u) == 0);
+    const bool even = (M2 & 1) == 0;
+    const bool vec_in = even && ((reinterpret_cast<uintptr_t>(in) & 15u) == 0);
+    float4 *lds4 = reinterpret_cast<float4 *>(asx_lds);
 
-    const int nelem = M1 << logT;
-    for (int e = threadIdx.x; e < nelem; e += ASX_THREADS) {
-        const int c = e & (T - 1), j1 = e >> logT;
-        const int j2 = c0 + c;
-        float2 v = make_float2(0.f, 0.f);
+    const int nelem4 = M1 << logH;
+    for (int e = threadIdx.x; e < nelem4; e += blockDim.x) {
+        const int cg = e & (H - 1), j1 = e >> logH;
+        const int j2 = c0 + 2 * cg;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (j2 < M2) {
             const uint32_t i0 = 2u * ((uint32_t)j1 * (uint32_t)M2 + (uint32_t)j2);
-            if (vec_ok && i0 + 1u < valid && i0 + 1u < period) {
-                v = *reinterpret_cast<const float2 *>(in + i0);
+            if (vec_in && i0 + 3u < valid && i0 + 3u < period) {
+                v = *reinterpret_cast<const float4 *>(in + i0);
             } else {
-                if (i0 < valid) v.x = in[i0 < period ? i0 : i0 - period];
-                if (i0 + 1u < valid) v.y = in[i0 + 1u < period ? i0 + 1u : i0 + 1u - period];
+                float r[4] = { 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+                for (int h = 0; h < 4; h++) {
+                    const uint32_t idx = i0 + h;
+                    if (j2 + (h >> 1) < M2 && idx < valid) r[h] = in[idx < period ? idx : idx - period];
+                }
+                v = make_float4(r[0], r[1], r[2], r[3]);
             }
         }
-        asx_lds[e] = v;
+        lds4[e] = v;
     }
     __syncthreads();
-    lds_fft<false, true>(asx_lds, P.st1, T, logT, T, 1, P.tw1);
+    lds_fft<MAXR, false, 2, true, true>(asx_lds, P.st1, col_layout(P), P.tw1);
 
-    // slot p1 holds frequency k1 = k1_of_pos1[p1]; it stays in that slot in HBM.
-    for (int e = threadIdx.x; e < nelem; e += ASX_THREADS) {
-        const int c = e & (T - 1), p1 = e >> logT;
-        const int j2 = c0 + c;
+    // slot p1 holds frequency k1 = k1_of_pos1[p1] and stays in that slot in HBM; the
+    // four-step twiddle w_M^(k1*j2) is applied by k_rows, where k1 is block-uniform.
+    for (int e = threadIdx.x; e < nelem4; e += blockDim.x) {
+        const int cg = e & (H - 1), p1 = e >> logH;
+        const int j2 = c0 + 2 * cg;
         if (j2 < M2) {
-            const uint32_t k1 = (uint32_t)P.k1_of_pos1[p1];
-            const float2 w = tw_F(P, 2u * k1 * (uint32_t)j2); // w_M^(k1*j2)
-            out[(size_t)p1 * M2 + j2] = cmul(asx_lds[e], w);
+            const float4 v = lds4[e];
+            float2 *o = out + (size_t)p1 * M2 + j2;
+            if (even) {
+                *reinterpret_cast<float4 *>(o) = v;
+            } else {
+                o[0] = make_float2(v.x, v.y);
+                if (j2 + 1 < M2) o[1] = make_float2(v.z, v.w);
+            }
         }
     }
 }
 
 // ---------------------------------------------------------------------------
-// k_rows: grid (M1/2 + 1, npairs).  Block rp handles spectrum rows k1 = rp and
-// m1 = M1 - rp (the rows that hold each other's k <-> M-k partners).
-// LDS: 4 rows of pitch M2: [Xa, Ya, Xb, Yb]; self-paired rows use [Xa, Ya].
+// k_rows: grid (M1/2 + 1, npairs).  Block k1 handles spectrum rows k1 and m1 = M1 - k1
+// (the rows that hold each other's k <-> M-k partners).  LDS: A[M2], B[M2] float4 with
+// A[e] = {X_k1[e], Y_k1[e]}, B[e] = {X_m1[e], Y_m1[e]}: the two spectra of a row travel
+// together (one b128 access, shared twiddles).  Self-paired rows (k1 = 0, M1/2) use A only.
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ void combine_pair(float2 ax, float2 bx, float2 ay, float2 by, float2 w,
                                              float2 &Gk, float2 &Gm)
@@ -107,83 +138,116 @@ __device__ __forceinline__ void combine_pair(float2 ax, float2 bx, float2 ay, fl
     Gm = make_float2(S.x + V.y, V.x - S.y);
 }
 
-__global__ __launch_bounds__(ASX_THREADS) void k_rows(AsxDev P, const float2 *__restrict__ zxa,
-                                                       const float2 *__restrict__ zya,
-                                                       float2 *__restrict__ ga)
+template <int MAXR>
+__global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_rows(const AsxDev *__restrict__ Pp, const float2 *__restrict__ zxa,
+                                                               const float2 *__restrict__ zya,
+                                                               float2 *__restrict__ ga)
 {
+    const AsxDev &P = *Pp; // plan constants live in device memory: uniform scalar loads
     const int M1 = P.M1, M2 = P.M2;
     const int k1 = blockIdx.x;
     const int m1 = (M1 - k1) % M1;
     const bool self = (k1 == m1);
     const size_t pair = blockIdx.y;
     const int pa = P.pos1_of_k1[k1], pb = P.pos1_of_k1[m1];
-    const int pitch = M2;
-    float2 *Xa = asx_lds, *Ya = asx_lds + pitch, *Xb = asx_lds + 2 * pitch, *Yb = asx_lds + 3 * pitch;
+    float4 *A4 = reinterpret_cast<float4 *>(asx_lds), *B4 = A4 + M2;
+    float2 *A2 = asx_lds, *B2 = asx_lds + 2 * M2; // .xy of slot e is A2[2e]
+
+    // Four-step twiddle of row k1: w_M^(k1*j2) with j2 = t + blockDim*i factors into
+    // w_M^(k1*t) (one two-level lookup per thread) times w_M^(k1*blockDim*i) (a handful per block).
+    __shared__ float2 tw_step[2][ASX_ROW_STEPS];
+    const int nsteps = (M2 + (int)blockDim.x - 1) / (int)blockDim.x;
+    if ((int)threadIdx.x < 2 * nsteps) {
+        const int which = (int)threadIdx.x >= nsteps;
+        const int i = threadIdx.x - which * nsteps;
+        const uint32_t row = which ? (uint32_t)m1 : (uint32_t)k1;
+        tw_step[which][i] = tw_F(P, 2u * row * (uint32_t)(i * (int)blockDim.x));
+    }
+    const uint32_t tcol = threadIdx.x < (unsigned)M2 ? threadIdx.x : 0u;
+    const float2 twa = tw_F(P, 2u * (uint32_t)k1 * tcol);
+    const float2 twb = tw_F(P, 2u * (uint32_t)m1 * tcol);
+    __syncthreads();
 
     const float2 *gx = zxa + pair * (size_t)P.M, *gy = zya + pair * (size_t)P.M;
-    for (int j2 = threadIdx.x; j2 < M2; j2 += ASX_THREADS) {
-        Xa[j2] = gx[(size_t)pa * M2 + j2];
-        Ya[j2] = gy[(size_t)pa * M2 + j2];
+    for (int j2 = threadIdx.x, i = 0; j2 < M2; j2 += blockDim.x, i++) {
+        const float2 wa = cmul(twa, tw_step[0][i]);
+        const float2 x = cmul(gx[(size_t)pa * M2 + j2], wa), y = cmul(gy[(size_t)pa * M2 + j2], wa);
+        A4[j2] = make_float4(x.x, x.y, y.x, y.y);
         if (!self) {
-            Xb[j2] = gx[(size_t)pb * M2 + j2];
-            Yb[j2] = gy[(size_t)pb * M2 + j2];
+            const float2 wb = cmul(twb, tw_step[1][i]);
+            const float2 xb = cmul(gx[(size_t)pb * M2 + j2], wb), yb = cmul(gy[(size_t)pb * M2 + j2], wb);
+            B4[j2] = make_float4(xb.x, xb.y, yb.x, yb.y);
         }
     }
     __syncthreads();
-    lds_fft<false, false>(asx_lds, P.st2, self ? 2 : 4, 0, 1, pitch, P.tw2);
+    {
+        LdsLayout L;
+        L.ngroups = self ? 1 : 2; L.log_ngroups = 0;
+        L.elem_stride = 2; L.group_stride = 2 * M2; L.member_stride = 1;
+        lds_fft<MAXR, false, 2, true, false>(asx_lds, P.st2, L, P.tw2);
+    }
 
-    // ---- spectral combine, in place: G[k] -> Xa slot, G[M-k] -> Xb (or Xa) slot ----
+    // ---- spectral combine, in place: G[k] -> A[.].xy, G[M-k] -> B[.].xy (or A for self rows) ----
     const float2 wA = tw_F(P, (uint32_t)k1); // w_F^k1, block-uniform
     if (!self) {
-        for (int k2 = threadIdx.x; k2 < M2; k2 += ASX_THREADS) {
+        for (int k2 = threadIdx.x; k2 < M2; k2 += blockDim.x) {
             const int sa = P.pos2_of_k2[k2], sb = P.pos2_of_k2[M2 - 1 - k2];
             const float2 w = cmul(wA, P.tw_b[k2]); // w_F^(k1 + M1*k2)
+            const float4 a = A4[sa], b = B4[sb];
             float2 Gk, Gm;
-            combine_pair(Xa[sa], Xb[sb], Ya[sa], Yb[sb], w, Gk, Gm);
-            Xa[sa] = Gk;
-            Xb[sb] = Gm;
+            combine_pair(make_float2(a.x, a.y), make_float2(b.x, b.y), make_float2(a.z, a.w),
+                         make_float2(b.z, b.w), w, Gk, Gm);
+            A2[2 * sa] = Gk;
+            B2[2 * sb] = Gm;
         }
     } else if (k1 == 0) {
-        for (int k2 = threadIdx.x; k2 <= M2 / 2; k2 += ASX_THREADS) {
+        for (int k2 = threadIdx.x; k2 <= M2 / 2; k2 += blockDim.x) {
             if (k2 == 0) {
                 // DC and Nyquist bins are real: X[0] = Re Z0 + Im Z0, X[M] = Re Z0 - Im Z0
-                const float2 zx = Xa[0], zy = Ya[0];
-                const float P0 = (zx.x + zx.y) * (zy.x + zy.y);
-                const float PM = (zx.x - zx.y) * (zy.x - zy.y);
-                Xa[0] = make_float2(P0 + PM, P0 - PM);
+                const float4 z = A4[0];
+                const float P0 = (z.x + z.y) * (z.z + z.w);
+                const float PM = (z.x - z.y) * (z.z - z.w);
+                A2[0] = make_float2(P0 + PM, P0 - PM);
             } else {
                 const int m2 = M2 - k2;
                 const int sa = P.pos2_of_k2[k2], sb = P.pos2_of_k2[m2];
+                const float4 a = A4[sa], b = A4[sb];
                 float2 Gk, Gm;
-                combine_pair(Xa[sa], Xa[sb], Ya[sa], Ya[sb], P.tw_b[k2], Gk, Gm);
-                Xa[sa] = Gk;
-                if (m2 != k2) Xa[sb] = Gm;
+                combine_pair(make_float2(a.x, a.y), make_float2(b.x, b.y), make_float2(a.z, a.w),
+                             make_float2(b.z, b.w), P.tw_b[k2], Gk, Gm);
+                A2[2 * sa] = Gk;
+                if (m2 != k2) A2[2 * sb] = Gm;
             }
         }
     } else { // k1 == M1/2, M1 even
-        for (int k2 = threadIdx.x; k2 < (M2 + 1) / 2; k2 += ASX_THREADS) {
+        for (int k2 = threadIdx.x; k2 < (M2 + 1) / 2; k2 += blockDim.x) {
             const int m2 = M2 - 1 - k2;
             const int sa = P.pos2_of_k2[k2], sb = P.pos2_of_k2[m2];
             const float2 w = cmul(wA, P.tw_b[k2]);
+            const float4 a = A4[sa], b = A4[sb];
             float2 Gk, Gm;
-            combine_pair(Xa[sa], Xa[sb], Ya[sa], Ya[sb], w, Gk, Gm);
-            Xa[sa] = Gk;
-            if (m2 != k2) Xa[sb] = Gm;
+            combine_pair(make_float2(a.x, a.y), make_float2(b.x, b.y), make_float2(a.z, a.w),
+                         make_float2(b.z, b.w), w, Gk, Gm);
+            A2[2 * sa] = Gk;
+            if (m2 != k2) A2[2 * sb] = Gm;
         }
     }
     __syncthreads();
 
-    // inverse row transforms of G (slots 0 and 2), digit-reversed in -> natural j2 out
-    lds_fft<true, false>(asx_lds, P.st2, self ? 1 : 2, 0, 1, 2 * pitch, P.tw2);
+    // inverse row transforms of G (the .xy halves of A and B), digit-reversed in -> natural j2 out
+    {
+        LdsLayout L;
+        L.ngroups = 1; L.log_ngroups = 0;
+        L.elem_stride = 2; L.group_stride = 0; L.member_stride = 2 * M2;
+        if (self) lds_fft<MAXR, true, 1, false, false>(asx_lds, P.st2, L, P.tw2);
+        else lds_fft<MAXR, true, 2, false, false>(asx_lds, P.st2, L, P.tw2);
+    }
 
+    // inverse four-step twiddle conj(w_M^(k1*j2)), same factors
     float2 *go = ga + pair * (size_t)P.M;
-    for (int j2 = threadIdx.x; j2 < M2; j2 += ASX_THREADS) {
-        const float2 wa = tw_F(P, 2u * (uint32_t)k1 * (uint32_t)j2); // conj(w_M^(k1*j2)) applied below
-        go[(size_t)pa * M2 + j2] = cmulc(Xa[j2], wa);
-        if (!self) {
-            const float2 wb = tw_F(P, 2u * (uint32_t)m1 * (uint32_t)j2);
-            go[(size_t)pb * M2 + j2] = cmulc(Xb[j2], wb);
-        }
+    for (int j2 = threadIdx.x, i = 0; j2 < M2; j2 += blockDim.x, i++) {
+        go[(size_t)pa * M2 + j2] = cmulc(A2[2 * j2], cmul(twa, tw_step[0][i]));
+        if (!self) go[(size_t)pb * M2 + j2] = cmulc(B2[2 * j2], cmul(twb, tw_step[1][i]));
     }
 }
 
@@ -197,6 +261,22 @@ __device__ __forceinline__ double wave_sum(double v)
 // ---------------------------------------------------------------------------
 // peak search helpers (src/cross_correlation.c:52-67)
 // ---------------------------------------------------------------------------
+// key(0) = arr[0] SIGNED (:56), key(i) = fabs(arr[i]) (:59).  A NaN key never wins the strict
+// '>' of :60 (so it needs no mapping in a running maximum); a NaN at index 0 is never beaten.
+__device__ __forceinline__ float peak_key_of(float value, uint32_t idx)
+{
+    const float a = fabsf(value);
+    const float z = (value != value) ? INFINITY : (value + 0.0f); // -0.0 -> +0.0 so it ties with |0|
+    return idx == 0u ? z : a;
+}
+__device__ __forceinline__ asx_peak_t peak_pack_key(float key, uint32_t idx)
+{
+    if (key != key) key = -INFINITY;
+    uint32_t b = __float_as_uint(key);
+    b = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+    return ((asx_peak_t)b << 32) | (asx_peak_t)(0xFFFFFFFFu - idx);
+}
+
 __device__ __forceinline__ asx_peak_t peak_pack(float value, uint32_t idx)
 {
     // key(0) = arr[0] SIGNED (:56), key(i) = fabs(arr[i]) (:59).  NaN never wins (:60),
@@ -225,7 +305,7 @@ __device__ __forceinline__ asx_peak_t wave_peak_max(asx_peak_t v)
     return v;
 }
 
-// block-wide max; result valid in thread 0.  `scratch` = 4 entries of LDS.
+// block-wide max; result valid in thread 0.  `scratch` = one entry per wave of the block.
 __device__ __forceinline__ asx_peak_t block_peak_max(asx_peak_t v, asx_peak_t *scratch)
 {
     v = wave_peak_max(v);
@@ -233,7 +313,8 @@ __device__ __forceinline__ asx_peak_t block_peak_max(asx_peak_t v, asx_peak_t *s
     if (lane == 0) scratch[wave] = v;
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int w = 1; w < ASX_THREADS / 64; w++) v = peak_max(v, scratch[w]);
+        const int nwaves = (blockDim.x + 63) >> 6;
+        for (int w = 1; w < nwaves; w++) v = peak_max(v, scratch[w]);
     }
     return v;
 }
@@ -255,46 +336,67 @@ __device__ __forceinline__ float near_max_threshold(float kmax)
     return kmax > 0.f ? kmax * (1.0f - ASX_REFINE_EPS) : kmax;
 }
 
-__global__ __launch_bounds__(ASX_THREADS) void k_inv_cols(AsxDev P, const float2 *__restrict__ ga,
-                                                           AsxPeakWs W, float *__restrict__ r_out)
+template <int MAXR>
+__global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_inv_cols(const AsxDev *__restrict__ Pp, const float2 *__restrict__ ga,
+                                                                   AsxPeakWs W, float *__restrict__ r_out)
 {
-    __shared__ asx_peak_t red[ASX_THREADS / 64];
+    const AsxDev &P = *Pp; // plan constants live in device memory: uniform scalar loads
+    __shared__ asx_peak_t red[ASX_FFT_THREADS_MAX / 64];
     __shared__ asx_peak_t tile_best;
     __shared__ uint32_t ncand;
     __shared__ AsxCand lcand[ASX_CAND_TILE];
     const int tile = blockIdx.x;
     const size_t pair = blockIdx.y;
-    const int T = P.T, logT = P.logT, M1 = P.M1, M2 = P.M2;
+    const int T = P.T, logH = P.logT - 1, H = T >> 1, M1 = P.M1, M2 = P.M2;
     const int c0 = tile * T;
     const float2 *in = ga + pair * (size_t)P.M;
+    const bool even = (M2 & 1) == 0;
+    float4 *lds4 = reinterpret_cast<float4 *>(asx_lds);
 
-    const int nelem = M1 << logT;
-    for (int e = threadIdx.x; e < nelem; e += ASX_THREADS) {
-        const int c = e & (T - 1), p1 = e >> logT;
-        const int j2 = c0 + c;
-        asx_lds[e] = (j2 < M2) ? in[(size_t)p1 * M2 + j2] : make_float2(0.f, 0.f);
+    const int nelem4 = M1 << logH;
+    for (int e = threadIdx.x; e < nelem4; e += blockDim.x) {
+        const int cg = e & (H - 1), p1 = e >> logH;
+        const int j2 = c0 + 2 * cg;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (j2 < M2) {
+            const float2 *g = in + (size_t)p1 * M2 + j2;
+            if (even) {
+                v = *reinterpret_cast<const float4 *>(g);
+            } else {
+                const float2 a = g[0];
+                const float2 b = (j2 + 1 < M2) ? g[1] : make_float2(0.f, 0.f);
+                v = make_float4(a.x, a.y, b.x, b.y);
+            }
+        }
+        lds4[e] = v;
     }
     if (threadIdx.x == 0) ncand = 0;
     __syncthreads();
-    lds_fft<true, true>(asx_lds, P.st1, T, logT, T, 1, P.tw1);
+    lds_fft<MAXR, true, 2, true, true>(asx_lds, P.st1, col_layout(P), P.tw1);
 
-    asx_peak_t best = 0;
-    for (int e = threadIdx.x; e < nelem; e += ASX_THREADS) {
-        const int c = e & (T - 1), j1 = e >> logT;
-        const int j2 = c0 + c;
+    // running maximum per thread: a thread meets its lags in increasing order, so the strict
+    // '>' keeps the earliest of equal keys, like the reference's sequential scan.
+    float best_key = -INFINITY;
+    uint32_t best_idx = 0xFFFFFFFFu;
+    for (int e = threadIdx.x; e < nelem4; e += blockDim.x) {
+        const int cg = e & (H - 1), j1 = e >> logH;
+        const int j2 = c0 + 2 * cg;
         if (j2 < M2) {
             const uint32_t i0 = 2u * ((uint32_t)j1 * (uint32_t)M2 + (uint32_t)j2);
-            const float2 g = asx_lds[e];
-            if (i0 < P.nout) {
-                best = peak_max(best, peak_pack(g.x, i0));
-                if (r_out) r_out[pair * (size_t)P.nout + i0] = g.x;
-            }
-            if (i0 + 1u < P.nout) {
-                best = peak_max(best, peak_pack(g.y, i0 + 1u));
-                if (r_out) r_out[pair * (size_t)P.nout + i0 + 1u] = g.y;
+            const float4 g = lds4[e];
+            const float val[4] = { g.x, g.y, g.z, g.w };
+#pragma unroll
+            for (int h = 0; h < 4; h++) {
+                const uint32_t idx = i0 + h;
+                if (idx < P.nout && j2 + (h >> 1) < M2) {
+                    const float key = peak_key_of(val[h], idx);
+                    if (key > best_key) { best_key = key; best_idx = idx; }
+                    if (r_out) r_out[pair * (size_t)P.nout + idx] = val[h];
+                }
             }
         }
     }
+    asx_peak_t best = best_idx == 0xFFFFFFFFu ? 0 : peak_pack_key(best_key, best_idx);
     best = block_peak_max(best, red);
     if (threadIdx.x == 0) tile_best = best;
     __syncthreads();
@@ -302,17 +404,18 @@ __global__ __launch_bounds__(ASX_THREADS) void k_inv_cols(AsxDev P, const float2
     // second look at the tile (still in LDS): lags as large as the tile maximum within
     // float32 accuracy.  A lag near the GLOBAL maximum is necessarily near its tile's maximum.
     const float thr = near_max_threshold(peak_key(tile_best));
-    for (int e = threadIdx.x; e < nelem; e += ASX_THREADS) {
-        const int c = e & (T - 1), j1 = e >> logT;
-        const int j2 = c0 + c;
+    for (int e = threadIdx.x; e < nelem4; e += blockDim.x) {
+        const int cg = e & (H - 1), j1 = e >> logH;
+        const int j2 = c0 + 2 * cg;
         if (j2 < M2) {
             const uint32_t i0 = 2u * ((uint32_t)j1 * (uint32_t)M2 + (uint32_t)j2);
-            const float2 g = asx_lds[e];
+            const float4 g = lds4[e];
+            const float val[4] = { g.x, g.y, g.z, g.w };
 #pragma unroll
-            for (int h = 0; h < 2; h++) {
+            for (int h = 0; h < 4; h++) {
                 const uint32_t idx = i0 + h;
-                if (idx < P.nout) {
-                    const float key = peak_key(peak_pack(h ? g.y : g.x, idx));
+                if (idx < P.nout && j2 + (h >> 1) < M2) {
+                    const float key = peak_key_of(val[h], idx);
                     if (key >= thr) {
                         const uint32_t slot = atomicAdd(&ncand, 1u);
                         if (slot < ASX_CAND_TILE) { lcand[slot].idx = idx; lcand[slot].key = key; }
@@ -354,8 +457,9 @@ __device__ __forceinline__ AsxSeg make_seg(uint32_t peak, uint32_t N)
     return s;
 }
 
-__global__ __launch_bounds__(ASX_THREADS) void k_finalize(AsxDev P, AsxPeakWs W, AsxSeg *__restrict__ seg)
+__global__ __launch_bounds__(ASX_THREADS) void k_finalize(const AsxDev *__restrict__ Pp, AsxPeakWs W, AsxSeg *__restrict__ seg)
 {
+    const AsxDev &P = *Pp; // plan constants live in device memory: uniform scalar loads
     __shared__ asx_peak_t red[ASX_THREADS / 64];
     __shared__ asx_peak_t pair_best;
     __shared__ uint32_t nsel, overflow;
@@ -401,9 +505,10 @@ __global__ __launch_bounds__(ASX_THREADS) void k_finalize(AsxDev P, AsxPeakWs W,
 // ---------------------------------------------------------------------------
 
 template <typename TIn>
-__global__ __launch_bounds__(ASX_THREADS) void k_refine_dots(AsxDev P, const TIn *__restrict__ src,
+__global__ __launch_bounds__(ASX_THREADS) void k_refine_dots(const AsxDev *__restrict__ Pp, const TIn *__restrict__ src,
                                                               const TIn *__restrict__ smp, AsxPeakWs W)
 {
+    const AsxDev &P = *Pp; // plan constants live in device memory: uniform scalar loads
     __shared__ double red[ASX_THREADS / 64];
     const size_t pair = blockIdx.y;
     if (blockIdx.x >= W.refine_n[pair]) return;
@@ -429,8 +534,9 @@ __global__ __launch_bounds__(ASX_THREADS) void k_refine_dots(AsxDev P, const TIn
 }
 
 // grid (npairs), one thread decides: the reference's max_abs_index rule on the exact values
-__global__ __launch_bounds__(64) void k_refine_pick(AsxDev P, AsxPeakWs W, AsxSeg *__restrict__ seg)
+__global__ __launch_bounds__(64) void k_refine_pick(const AsxDev *__restrict__ Pp, AsxPeakWs W, AsxSeg *__restrict__ seg)
 {
+    const AsxDev &P = *Pp; // plan constants live in device memory: uniform scalar loads
     const size_t pair = blockIdx.x;
     const uint32_t n = W.refine_n[pair];
     if (n < 2u || threadIdx.x != 0) return;
@@ -587,44 +693,98 @@ __global__ __launch_bounds__(ASX_THREADS) void k_synth(uint64_t seed, uint64_t f
 size_t asx_lds_bytes_cols(const AsxDev &P) { return (size_t)P.M1 * P.T * sizeof(float2); }
 size_t asx_lds_bytes_rows(const AsxDev &P) { return (size_t)4 * P.M2 * sizeof(float2); }
 
+// Block size: a multiple of 64 (<= ASX_FFT_THREADS_MAX).  First enough waves per CU to hide
+// LDS/HBM latency given how many blocks the LDS footprint admits (target >= 12 waves per CU),
+// then the size that wastes the fewest thread slots over the stages (each stage has
+// `groups * n / radix` work items); ties go to the larger block.
+int asx_pick_threads(const AsxStages &st, int groups, int min_threads, size_t lds_bytes)
+{
+    long blocks_per_cu = lds_bytes ? (long)(160 * 1024 / lds_bytes) : 8;
+    if (blocks_per_cu < 1) blocks_per_cu = 1;
+    if (blocks_per_cu > 8) blocks_per_cu = 8;
+    int want = 64 * (int)((12 + blocks_per_cu - 1) / blocks_per_cu);
+    if (want > ASX_FFT_THREADS_MAX) want = ASX_FFT_THREADS_MAX;
+    if (min_threads < want) min_threads = want;
+    long best_cost = -1;
+    int best = ASX_FFT_THREADS_MAX;
+    for (int bd = 64; bd <= ASX_FFT_THREADS_MAX; bd += 64) {
+        if (bd < min_threads) continue;
+        long cost = 0;
+        for (int i = 0; i < st.nstages; i++) {
+            const long items = (long)groups * st.nbf[i];
+            cost += (items + bd - 1) / bd * bd;
+        }
+        if (st.nstages == 0) cost = bd;
+        if (best_cost < 0 || cost <= best_cost) { best_cost = cost; best = bd; }
+    }
+    return best;
+}
+
+static int max_radix(const AsxStages &st)
+{
+    int m = 2;
+    for (int i = 0; i < st.nstages; i++) m = st.radix[i] > m ? st.radix[i] : m;
+    return m;
+}
+
+static void allow_big_lds(const void *fn, size_t bytes)
+{
+    if (bytes > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
 void asx_launch_fwd_cols(const AsxDev &P, const float *src, const float *smp, float2 *zxa,
                          float2 *zya, int npairs, hipStream_t s)
 {
     dim3 grid(P.ntiles, 2, npairs);
-    hipLaunchKernelGGL(k_fwd_cols, grid, dim3(ASX_THREADS), asx_lds_bytes_cols(P), s, P, src, smp, zxa, zya);
+#define ASX_LAUNCH(MAXR) \
+    do { allow_big_lds((const void *)k_fwd_cols<MAXR>, asx_lds_bytes_cols(P)); \
+         hipLaunchKernelGGL(k_fwd_cols<MAXR>, grid, dim3(P.threads_cols), asx_lds_bytes_cols(P), s, P.self_dev, src, smp, zxa, zya); } while (0)
+    const int mr = max_radix(P.st1);
+    if (mr <= 10) ASX_LAUNCH(10); else if (mr <= 12) ASX_LAUNCH(12); else ASX_LAUNCH(16);
+#undef ASX_LAUNCH
 }
 
 void asx_launch_rows(const AsxDev &P, const float2 *zxa, const float2 *zya, float2 *ga, int npairs,
                      hipStream_t s)
 {
     dim3 grid(P.M1 / 2 + 1, npairs);
-    hipLaunchKernelGGL(k_rows, grid, dim3(ASX_THREADS), asx_lds_bytes_rows(P), s, P, zxa, zya, ga);
+#define ASX_LAUNCH(MAXR) \
+    do { allow_big_lds((const void *)k_rows<MAXR>, asx_lds_bytes_rows(P)); \
+         hipLaunchKernelGGL(k_rows<MAXR>, grid, dim3(P.threads_rows), asx_lds_bytes_rows(P), s, P.self_dev, zxa, zya, ga); } while (0)
+    const int mr = max_radix(P.st2);
+    if (mr <= 10) ASX_LAUNCH(10); else if (mr <= 12) ASX_LAUNCH(12); else ASX_LAUNCH(16);
+#undef ASX_LAUNCH
 }
 
 void asx_launch_inv_cols(const AsxDev &P, const float2 *ga, const AsxPeakWs &W, float *r_out, int npairs,
                          hipStream_t s)
 {
     dim3 grid(P.ntiles, npairs);
-    hipLaunchKernelGGL(k_inv_cols, grid, dim3(ASX_THREADS), asx_lds_bytes_cols(P), s, P, ga, W, r_out);
+#define ASX_LAUNCH(MAXR) \
+    do { allow_big_lds((const void *)k_inv_cols<MAXR>, asx_lds_bytes_cols(P)); \
+         hipLaunchKernelGGL(k_inv_cols<MAXR>, grid, dim3(P.threads_cols), asx_lds_bytes_cols(P), s, P.self_dev, ga, W, r_out); } while (0)
+    const int mr = max_radix(P.st1);
+    if (mr <= 10) ASX_LAUNCH(10); else if (mr <= 12) ASX_LAUNCH(12); else ASX_LAUNCH(16);
+#undef ASX_LAUNCH
 }
 
 void asx_launch_finalize(const AsxDev &P, const AsxPeakWs &W, AsxSeg *seg, int npairs, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_finalize, dim3(npairs), dim3(ASX_THREADS), 0, s, P, W, seg);
+    hipLaunchKernelGGL(k_finalize, dim3(npairs), dim3(ASX_THREADS), 0, s, P.self_dev, W, seg);
 }
 
 void asx_launch_refine_f32(const AsxDev &P, const float *src, const float *smp, const AsxPeakWs &W,
                            AsxSeg *seg, int npairs, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_refine_dots<float>, dim3(ASX_CAND_PAIR, npairs), dim3(ASX_THREADS), 0, s, P, src, smp, W);
-    hipLaunchKernelGGL(k_refine_pick, dim3(npairs), dim3(64), 0, s, P, W, seg);
+    hipLaunchKernelGGL(k_refine_dots<float>, dim3(ASX_CAND_PAIR, npairs), dim3(ASX_THREADS), 0, s, P.self_dev, src, smp, W);
+    hipLaunchKernelGGL(k_refine_pick, dim3(npairs), dim3(64), 0, s, P.self_dev, W, seg);
 }
 
 void asx_launch_refine_f64(const AsxDev &P, const double *src, const double *smp, const AsxPeakWs &W,
                            AsxSeg *seg, int npairs, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_refine_dots<double>, dim3(ASX_CAND_PAIR, npairs), dim3(ASX_THREADS), 0, s, P, src, smp, W);
-    hipLaunchKernelGGL(k_refine_pick, dim3(npairs), dim3(64), 0, s, P, W, seg);
+    hipLaunchKernelGGL(k_refine_dots<double>, dim3(ASX_CAND_PAIR, npairs), dim3(ASX_THREADS), 0, s, P.self_dev, src, smp, W);
+    hipLaunchKernelGGL(k_refine_pick, dim3(npairs), dim3(64), 0, s, P.self_dev, W, seg);
 }
 
 void asx_launch_pearson_f32(const float *src, const float *smp, size_t src_pitch, size_t smp_pitch,

@@ -18,7 +18,7 @@ c_intp = ctypes.POINTER(ctypes.c_int)
 # every symbol include/audiosync/xcorr_hip.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
     "asx_device_count", "asx_last_error", "asx_abi_version", "asx_plan_create", "asx_plan_create_ex", "asx_plan_destroy",
-    "asx_plan_sample_len", "asx_plan_fft_len", "asx_plan_split", "asx_plan_group",
+    "asx_plan_sample_len", "asx_plan_fft_len", "asx_plan_split", "asx_plan_threads", "asx_plan_group",
     "asx_plan_workspace_bytes", "asx_xcorr_f64", "asx_xcorr_batch_f32", "asx_xcorr_batch_f32_dev",
     "asx_xcorr_debug_r_dev", "asx_pearson_f64", "asx_synth_pairs_dev", "asx_plan_set_profiling",
     "asx_plan_last_timings_ms", "asx_device_malloc", "asx_device_free", "asx_memcpy_h2d",
@@ -67,6 +67,8 @@ def lib():
     for name in ("asx_plan_sample_len", "asx_plan_fft_len", "asx_plan_group", "asx_plan_workspace_bytes"):
         getattr(L, name).restype = ctypes.c_size_t
         getattr(L, name).argtypes = [vp]
+    L.asx_plan_threads.restype = ctypes.c_int
+    L.asx_plan_threads.argtypes = [vp, c_intp, c_intp]
     L.asx_plan_split.restype = ctypes.c_int
     L.asx_plan_split.argtypes = [vp, c_intp, c_intp, c_intp]
     L.asx_xcorr_f64.restype = ctypes.c_int
@@ -218,6 +220,12 @@ class Plan:
         a, b, c = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
         lib().asx_plan_split(self._h, a, b, c)
         return a.value, b.value, c.value
+
+    @property
+    def threads(self):
+        a, b = ctypes.c_int(), ctypes.c_int()
+        lib().asx_plan_threads(self._h, a, b)
+        return a.value, b.value
 
     def xcorr_f64(self, source, sample):
         """the reference's calling convention: -> (ret, lag, coefficient)"""

@@ -104,7 +104,7 @@ def test_known_answers_with_every_split(mod, kat):
             if M % m1 or m1 > 64 or M // m1 > 1024:
                 continue
             m2 = M // m1
-            t = 1
+            t = 2
             while t * 2 <= min(m2, 16):
                 t *= 2
             with mod.Plan(n, 1, 0, split="%dx%dx%d" % (m1, m2, t)) as plan:
