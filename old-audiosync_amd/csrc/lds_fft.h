@@ -10,8 +10,10 @@
 //
 // Radices 2,3,4,5 are hand-written; 6,8,9,10,12,15,16 are built from them at
 // compile time (one Cooley-Tukey step in registers, constant inner twiddles),
-// so a length of 800..2000 takes THREE passes over LDS instead of five or six
-// -- LDS bandwidth, not HBM, is what the row kernel runs out of first.
+// so a length of 800..2000 takes THREE passes over LDS (three barriers) instead
+// of five or six.  The path is VALU-issue bound on gfx950 (one wave64 VALU
+// instruction per 4 cycles per SIMD), so everything here is written to issue
+// packed (v_pk_*) arithmetic on two transforms at once without lane swizzles.
 // Stage twiddles w^(j*u) come from ONE (or two) table reads per butterfly and
 // a short product tree (depth <= 3), not R-1 gathered reads.
 // Index algebra is modelled and tested in tests/model_fourstep.py.
@@ -23,9 +25,6 @@
 
 #include <type_traits>
 
-#ifndef ASX_WIDE_MAXR
-#define ASX_WIDE_MAXR 10   // largest radix whose two members are held in registers together
-#endif
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b)
 {
@@ -89,22 +88,64 @@ template <int R, int M> struct Root {
     static constexpr float im = (float)(-asx_ct_sin(2.0 * asx_ct_pi * (double)ms / (double)R));
 };
 
-// a * w_R^M (forward) or a * conj(w_R^M) (INV)
-template <int R, int M, bool INV> __device__ __forceinline__ float2 mul_root(float2 a)
+// ---------------------------------------------------------------------------
+// Pair-planar complex arithmetic.  Every thread transforms TWO sequences at once (two
+// adjacent tile columns; or the X and Y spectra of one row; or the two rows of G): the
+// real parts of the pair share one 64-bit register pair, the imaginary parts another:
+//     Cx2.re = (re of member 0, re of member 1),  Cx2.im = (im of member 0, im of member 1)
+// so every complex add is two v_pk_add_f32, every multiply by a (shared) twiddle is four
+// v_pk_mul/fma_f32, and multiplications by +-i or conjugations are register renames with
+// sign modifiers -- no lane swizzles (the interleaved re/im layout cost ~25% v_mov's).
+// In LDS an element pair is one float4 {re0, re1, im0, im1}: one ds_read_b128 fills a Cx2.
+// ---------------------------------------------------------------------------
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+struct Cx2 {
+    v2f re, im;
+};
+
+__device__ __forceinline__ Cx2 operator+(Cx2 a, Cx2 b) { return Cx2{ a.re + b.re, a.im + b.im }; }
+__device__ __forceinline__ Cx2 operator-(Cx2 a, Cx2 b) { return Cx2{ a.re - b.re, a.im - b.im }; }
+// multiply by -i: (re, im) -> (im, -re);  by +i: (-im, re)
+__device__ __forceinline__ Cx2 mul_neg_i(Cx2 a) { return Cx2{ a.im, -a.re }; }
+__device__ __forceinline__ Cx2 mul_pos_i(Cx2 a) { return Cx2{ -a.im, a.re }; }
+template <bool INV> __device__ __forceinline__ Cx2 rot(Cx2 a) { return INV ? mul_pos_i(a) : mul_neg_i(a); }
+// by a scalar twiddle shared by both members: a * w, a * conj(w)
+__device__ __forceinline__ Cx2 mulw(Cx2 a, float2 w)
+{
+    return Cx2{ a.re * w.x - a.im * w.y, a.re * w.y + a.im * w.x };
+}
+__device__ __forceinline__ Cx2 mulwc(Cx2 a, float2 w)
+{
+    return Cx2{ a.re * w.x + a.im * w.y, a.im * w.x - a.re * w.y };
+}
+// member-wise complex products (different twiddle per member)
+__device__ __forceinline__ Cx2 mul2(Cx2 a, Cx2 w) { return Cx2{ a.re * w.re - a.im * w.im, a.re * w.im + a.im * w.re }; }
+__device__ __forceinline__ Cx2 mul2c(Cx2 a, Cx2 w) { return Cx2{ a.re * w.re + a.im * w.im, a.im * w.re - a.re * w.im }; }
+
+__device__ __forceinline__ Cx2 lds_get(const float4 *p)
+{
+    const float4 x = *p;
+    return Cx2{ v2f{ x.x, x.y }, v2f{ x.z, x.w } };
+}
+__device__ __forceinline__ void lds_put(float4 *p, Cx2 v) { *p = make_float4(v.re.x, v.re.y, v.im.x, v.im.y); }
+
+// a * w_R^M (forward) or a * conj(w_R^M) (INV), compile-time root
+template <int R, int M, bool INV> __device__ __forceinline__ Cx2 mul_root(Cx2 a)
 {
     constexpr int m = ((M % R) + R) % R;
     if constexpr (m == 0) {
         return a;
     } else if constexpr (2 * m == R) {
-        return make_float2(-a.x, -a.y);
+        return Cx2{ -a.re, -a.im };
     } else if constexpr (4 * m == R) { // w = -i ; conj = +i
-        return INV ? make_float2(-a.y, a.x) : make_float2(a.y, -a.x);
+        return INV ? mul_pos_i(a) : mul_neg_i(a);
     } else if constexpr (4 * m == 3 * R) { // w = +i
-        return INV ? make_float2(a.y, -a.x) : make_float2(-a.y, a.x);
+        return INV ? mul_neg_i(a) : mul_pos_i(a);
     } else {
         constexpr float c = Root<R, m>::re;
         constexpr float s = INV ? -Root<R, m>::im : Root<R, m>::im;
-        return make_float2(a.x * c - a.y * s, a.x * s + a.y * c);
+        return Cx2{ a.re * c - a.im * s, a.re * s + a.im * c };
     }
 }
 
@@ -112,60 +153,58 @@ template <int R, int M, bool INV> __device__ __forceinline__ float2 mul_root(flo
 template <int R, bool INV> struct Bfly;
 
 template <bool INV> struct Bfly<2, INV> {
-    static __device__ __forceinline__ void run(float2 (&v)[2])
+    static __device__ __forceinline__ void run(Cx2 (&v)[2])
     {
-        float2 a = v[0], b = v[1];
-        v[0] = cadd(a, b);
-        v[1] = csub(a, b);
+        const Cx2 a = v[0], b = v[1];
+        v[0] = a + b;
+        v[1] = a - b;
     }
 };
 
 template <bool INV> struct Bfly<4, INV> {
-    static __device__ __forceinline__ void run(float2 (&v)[4])
+    static __device__ __forceinline__ void run(Cx2 (&v)[4])
     {
-        float2 s0 = cadd(v[0], v[2]), d0 = csub(v[0], v[2]);
-        float2 s1 = cadd(v[1], v[3]), d1 = csub(v[1], v[3]);
-        // forward: -i*d1 ; inverse: +i*d1
-        float2 r = INV ? make_float2(-d1.y, d1.x) : make_float2(d1.y, -d1.x);
-        v[0] = cadd(s0, s1);
-        v[2] = csub(s0, s1);
-        v[1] = cadd(d0, r);
-        v[3] = csub(d0, r);
+        const Cx2 s0 = v[0] + v[2], d0 = v[0] - v[2];
+        const Cx2 s1 = v[1] + v[3], d1 = v[1] - v[3];
+        const Cx2 r = rot<INV>(d1); // forward: -i*d1 ; inverse: +i*d1
+        v[0] = s0 + s1;
+        v[2] = s0 - s1;
+        v[1] = d0 + r;
+        v[3] = d0 - r;
     }
 };
 
 template <bool INV> struct Bfly<3, INV> {
-    static __device__ __forceinline__ void run(float2 (&v)[3])
+    static __device__ __forceinline__ void run(Cx2 (&v)[3])
     {
-        const float sn = 0.86602540378443864676f; // sin(2*pi/3)
-        float2 t1 = cadd(v[1], v[2]), t2 = csub(v[1], v[2]);
-        float2 m = make_float2(v[0].x - 0.5f * t1.x, v[0].y - 0.5f * t1.y);
-        float2 r = INV ? make_float2(-sn * t2.y, sn * t2.x) : make_float2(sn * t2.y, -sn * t2.x);
-        v[0] = cadd(v[0], t1);
-        v[1] = cadd(m, r);
-        v[2] = csub(m, r);
+        constexpr float sn = 0.86602540378443864676f; // sin(2*pi/3)
+        const Cx2 t1 = v[1] + v[2], t2 = v[1] - v[2];
+        const Cx2 m = Cx2{ v[0].re - 0.5f * t1.re, v[0].im - 0.5f * t1.im };
+        const Cx2 st = Cx2{ sn * t2.re, sn * t2.im };
+        const Cx2 r = rot<INV>(st);
+        v[0] = v[0] + t1;
+        v[1] = m + r;
+        v[2] = m - r;
     }
 };
 
 template <bool INV> struct Bfly<5, INV> {
-    static __device__ __forceinline__ void run(float2 (&v)[5])
+    static __device__ __forceinline__ void run(Cx2 (&v)[5])
     {
-        const float c1 = 0.30901699437494742410f, s1 = 0.95105651629515357212f;
-        const float c2 = -0.80901699437494742410f, s2 = 0.58778525229247312917f;
-        float2 a1 = cadd(v[1], v[4]), b1 = csub(v[1], v[4]);
-        float2 a2 = cadd(v[2], v[3]), b2 = csub(v[2], v[3]);
-        float2 m1 = make_float2(v[0].x + c1 * a1.x + c2 * a2.x, v[0].y + c1 * a1.y + c2 * a2.y);
-        float2 m2 = make_float2(v[0].x + c2 * a1.x + c1 * a2.x, v[0].y + c2 * a1.y + c1 * a2.y);
-        float2 u1 = make_float2(s1 * b1.x + s2 * b2.x, s1 * b1.y + s2 * b2.y);
-        float2 u2 = make_float2(s2 * b1.x - s1 * b2.x, s2 * b1.y - s1 * b2.y);
-        // forward: -i*u ; inverse: +i*u
-        float2 r1 = INV ? make_float2(-u1.y, u1.x) : make_float2(u1.y, -u1.x);
-        float2 r2 = INV ? make_float2(-u2.y, u2.x) : make_float2(u2.y, -u2.x);
-        v[0] = make_float2(v[0].x + a1.x + a2.x, v[0].y + a1.y + a2.y);
-        v[1] = cadd(m1, r1);
-        v[4] = csub(m1, r1);
-        v[2] = cadd(m2, r2);
-        v[3] = csub(m2, r2);
+        constexpr float c1 = 0.30901699437494742410f, s1 = 0.95105651629515357212f;
+        constexpr float c2 = -0.80901699437494742410f, s2 = 0.58778525229247312917f;
+        const Cx2 a1 = v[1] + v[4], b1 = v[1] - v[4];
+        const Cx2 a2 = v[2] + v[3], b2 = v[2] - v[3];
+        const Cx2 m1 = Cx2{ v[0].re + c1 * a1.re + c2 * a2.re, v[0].im + c1 * a1.im + c2 * a2.im };
+        const Cx2 m2 = Cx2{ v[0].re + c2 * a1.re + c1 * a2.re, v[0].im + c2 * a1.im + c1 * a2.im };
+        const Cx2 u1 = Cx2{ s1 * b1.re + s2 * b2.re, s1 * b1.im + s2 * b2.im };
+        const Cx2 u2 = Cx2{ s2 * b1.re - s1 * b2.re, s2 * b1.im - s1 * b2.im };
+        const Cx2 r1 = rot<INV>(u1), r2 = rot<INV>(u2); // forward: -i*u ; inverse: +i*u
+        v[0] = Cx2{ v[0].re + a1.re + a2.re, v[0].im + a1.im + a2.im };
+        v[1] = m1 + r1;
+        v[4] = m1 - r1;
+        v[2] = m2 + r2;
+        v[3] = m2 - r2;
     }
 };
 
@@ -174,21 +213,23 @@ template <bool INV> struct Bfly<5, INV> {
 //   w_R^(t*u) = w_R1^(t1*u1) * w_R^(t2*u1) * w_R2^(t2*u2)
 template <int R1, int R2, bool INV> struct BflyC {
     static constexpr int R = R1 * R2;
-    static __device__ __forceinline__ void run(float2 (&v)[R])
+    static __device__ __forceinline__ void run(Cx2 (&v)[R])
     {
         // DFT_R1 over t1 for every t2, then the inner twiddle w_R^(t2*u1)
         static_for<0, R2>([&](auto T2) __attribute__((always_inline)) {
             constexpr int t2 = decltype(T2)::value;
-            float2 x[R1];
+            Cx2 x[R1];
             static_for<0, R1>([&](auto T1) __attribute__((always_inline)) { x[T1] = v[R2 * T1 + t2]; });
             Bfly<R1, INV>::run(x);
-            static_for<0, R1>([&](auto U1) __attribute__((always_inline)) { v[R2 * U1 + t2] = mul_root<R, t2 * decltype(U1)::value, INV>(x[U1]); });
+            static_for<0, R1>([&](auto U1) __attribute__((always_inline)) {
+                v[R2 * U1 + t2] = mul_root<R, t2 * decltype(U1)::value, INV>(x[U1]);
+            });
         });
         // DFT_R2 over t2 for every u1; outputs land in natural order u = u1 + R1*u2
-        float2 y[R];
+        Cx2 y[R];
         static_for<0, R1>([&](auto U1) __attribute__((always_inline)) {
             constexpr int u1 = decltype(U1)::value;
-            float2 x[R2];
+            Cx2 x[R2];
             static_for<0, R2>([&](auto T2) __attribute__((always_inline)) { x[T2] = v[R2 * u1 + T2]; });
             Bfly<R2, INV>::run(x);
             static_for<0, R2>([&](auto U2) __attribute__((always_inline)) { y[u1 + R1 * U2] = x[U2]; });
@@ -226,36 +267,27 @@ template <int R> __device__ __forceinline__ void stage_twiddles(const float2 *__
 }
 
 // ---------------------------------------------------------------------------
-// One stage.  A work item is one butterfly position (sub-block b, offset j) of one
-// GROUP of CPT transforms that share the stage twiddles (generated once per work item):
-//   element e of member m of group g  ->  lds[g*group_stride + m*member_stride + e*elem_stride]
-//   ADJ  : CPT == 2 and member_stride == 1 with 16-byte aligned pairs: both members move
-//          with ONE ds_read_b128 / ds_write_b128 (column tiles: two adjacent columns;
-//          row tiles: the X and Y spectra interleaved)
-//   GFAST: consecutive lanes walk the group index first (ngroups is a power of two) so a
+// One stage.  The LDS image is an array of float4 slots; slot (g, e) = element e of the
+// transform PAIR g sits at lds4[g*group_stride + e*elem_stride].  A work item is one
+// butterfly position (sub-block b, offset j) of one pair.
+//   GFAST: consecutive lanes walk the pair index first (ngroups is a power of two) so a
 //          wave touches contiguous LDS in column tiles; otherwise lanes walk butterflies.
 //   UNIT_TW: the stage's twiddles are all 1 (q == 1, the innermost stage).
 // ---------------------------------------------------------------------------
 struct LdsLayout {
-    int ngroups, log_ngroups;  // groups of CPT transforms
-    int elem_stride;           // in float2 units
+    int ngroups, log_ngroups;  // transform pairs in the tile
+    int elem_stride;           // in float4 slots
     int group_stride;
-    int member_stride;
 };
 
-template <int R, bool INV, int CPT, bool ADJ, bool GFAST, bool UNIT_TW>
-__device__ __forceinline__ void lds_stage(float2 *lds, const AsxStages &st, int i, const LdsLayout &L,
+template <int R, bool INV, bool GFAST, bool UNIT_TW>
+__device__ __forceinline__ void lds_stage(float4 *lds, const AsxStages &st, int i, const LdsLayout &L,
                                           const float2 *__restrict__ tw)
 {
-    static_assert(!ADJ || CPT == 2, "ADJ means two adjacent members");
-    // both members in registers at once only while that fits 128 VGPRs; larger radices
-    // run the members one after the other (twiddles stay in registers either way)
-    constexpr bool WIDE = ADJ && (R <= ASX_WIDE_MAXR);
     const int ns = st.ns[i], q = st.q[i], nbf = st.nbf[i], twmul = st.twmul[i];
     const float inv_q = st.inv_q[i], inv_nbf = st.inv_nbf[i];
     const int total = L.ngroups * nbf;
     const int step = q * L.elem_stride;
-    const int mstride = ADJ ? 1 : L.member_stride;
     for (int w = threadIdx.x; w < total; w += blockDim.x) {
         int g, bf;
         if (GFAST) {
@@ -266,64 +298,44 @@ __device__ __forceinline__ void lds_stage(float2 *lds, const AsxStages &st, int 
         }
         int j;
         const int b = div_exact(bf, q, inv_q, j);
-        float2 *p = lds + g * L.group_stride + (b * ns + j) * L.elem_stride;
-        float2 tww[R];
-        if constexpr (!UNIT_TW) stage_twiddles<R>(tw, j * twmul, tww);
-
-        auto compute = [&](float2(&v)[R]) __attribute__((always_inline)) {
-            if constexpr (UNIT_TW) {
-                Bfly<R, INV>::run(v);
-            } else if constexpr (!INV) {
+        float4 *p = lds + g * L.group_stride + (b * ns + j) * L.elem_stride;
+        Cx2 v[R];
+        static_for<0, R>([&](auto T) __attribute__((always_inline)) { v[T] = lds_get(p + T * step); });
+        if constexpr (UNIT_TW) {
+            Bfly<R, INV>::run(v);
+        } else {
+            float2 tww[R];
+            stage_twiddles<R>(tw, j * twmul, tww);
+            if constexpr (!INV) {
                 Bfly<R, false>::run(v);
-                static_for<1, R>([&](auto U) __attribute__((always_inline)) { v[U] = cmul(v[U], tww[U]); });
+                static_for<1, R>([&](auto U) __attribute__((always_inline)) { v[U] = mulw(v[U], tww[U]); });
             } else {
-                static_for<1, R>([&](auto U) __attribute__((always_inline)) { v[U] = cmulc(v[U], tww[U]); });
+                static_for<1, R>([&](auto U) __attribute__((always_inline)) { v[U] = mulwc(v[U], tww[U]); });
                 Bfly<R, true>::run(v);
             }
-        };
-
-        if constexpr (WIDE) {
-            float2 v0[R], v1[R];
-            static_for<0, R>([&](auto T) __attribute__((always_inline)) {
-                const float4 x = *reinterpret_cast<const float4 *>(p + T * step);
-                v0[T] = make_float2(x.x, x.y);
-                v1[T] = make_float2(x.z, x.w);
-            });
-            compute(v0);
-            compute(v1);
-            static_for<0, R>([&](auto T) __attribute__((always_inline)) {
-                *reinterpret_cast<float4 *>(p + T * step) = make_float4(v0[T].x, v0[T].y, v1[T].x, v1[T].y);
-            });
-        } else {
-            static_for<0, CPT>([&](auto M) __attribute__((always_inline)) {
-                float2 v[R];
-                float2 *pm = p + M * mstride;
-                static_for<0, R>([&](auto T) __attribute__((always_inline)) { v[T] = pm[T * step]; });
-                compute(v);
-                static_for<0, R>([&](auto T) __attribute__((always_inline)) { pm[T * step] = v[T]; });
-            });
         }
+        static_for<0, R>([&](auto T) __attribute__((always_inline)) { lds_put(p + T * step, v[T]); });
     }
 }
 
-template <int R, bool INV, int CPT, bool ADJ, bool GFAST>
-__device__ __forceinline__ void lds_stage_r(float2 *lds, const AsxStages &st, int i, const LdsLayout &L,
+template <int R, bool INV, bool GFAST>
+__device__ __forceinline__ void lds_stage_r(float4 *lds, const AsxStages &st, int i, const LdsLayout &L,
                                             const float2 *__restrict__ tw)
 {
     if (st.q[i] == 1) // wave-uniform
-        lds_stage<R, INV, CPT, ADJ, GFAST, true>(lds, st, i, L, tw);
+        lds_stage<R, INV, GFAST, true>(lds, st, i, L, tw);
     else
-        lds_stage<R, INV, CPT, ADJ, GFAST, false>(lds, st, i, L, tw);
+        lds_stage<R, INV, GFAST, false>(lds, st, i, L, tw);
 }
 
 // MAXR: largest radix this kernel variant carries code for.  Register allocation is per
 // kernel, so a variant without the radix-15/16 bodies keeps the occupancy of the small ones.
-template <int MAXR, bool INV, int CPT, bool ADJ, bool GFAST>
-__device__ __forceinline__ void lds_stage_any(float2 *lds, const AsxStages &st, int i, const LdsLayout &L,
+template <int MAXR, bool INV, bool GFAST>
+__device__ __forceinline__ void lds_stage_any(float4 *lds, const AsxStages &st, int i, const LdsLayout &L,
                                               const float2 *__restrict__ tw)
 {
 #define ASX_STAGE_CASE(R) \
-    case R: if constexpr (R <= MAXR) lds_stage_r<R, INV, CPT, ADJ, GFAST>(lds, st, i, L, tw); break;
+    case R: if constexpr (R <= MAXR) lds_stage_r<R, INV, GFAST>(lds, st, i, L, tw); break;
     switch (st.radix[i]) { // wave-uniform
         ASX_STAGE_CASE(16)
         ASX_STAGE_CASE(15)
@@ -335,25 +347,25 @@ __device__ __forceinline__ void lds_stage_any(float2 *lds, const AsxStages &st, 
         ASX_STAGE_CASE(5)
         ASX_STAGE_CASE(4)
         ASX_STAGE_CASE(3)
-    default: lds_stage_r<2, INV, CPT, ADJ, GFAST>(lds, st, i, L, tw); break;
+    default: lds_stage_r<2, INV, GFAST>(lds, st, i, L, tw); break;
     }
 #undef ASX_STAGE_CASE
 }
 
 // Whole transform.  Caller has filled LDS and called __syncthreads(); on return
 // all lanes see the result (the routine ends with a barrier).
-template <int MAXR, bool INV, int CPT, bool ADJ, bool GFAST>
-__device__ __forceinline__ void lds_fft(float2 *lds, const AsxStages &st, const LdsLayout &L,
+template <int MAXR, bool INV, bool GFAST>
+__device__ __forceinline__ void lds_fft(float4 *lds, const AsxStages &st, const LdsLayout &L,
                                         const float2 *__restrict__ tw)
 {
     if (!INV) {
         for (int i = 0; i < st.nstages; i++) {
-            lds_stage_any<MAXR, false, CPT, ADJ, GFAST>(lds, st, i, L, tw);
+            lds_stage_any<MAXR, false, GFAST>(lds, st, i, L, tw);
             __syncthreads();
         }
     } else {
         for (int i = st.nstages - 1; i >= 0; i--) {
-            lds_stage_any<MAXR, true, CPT, ADJ, GFAST>(lds, st, i, L, tw);
+            lds_stage_any<MAXR, true, GFAST>(lds, st, i, L, tw);
             __syncthreads();
         }
     }

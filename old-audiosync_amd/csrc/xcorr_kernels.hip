@@ -31,17 +31,17 @@ __device__ __forceinline__ float2 tw_F(const AsxDev &P, uint32_t p)
 
 // ---------------------------------------------------------------------------
 // Column tiles.  A tile is T columns (T even, a power of two) of the [M1][M2] matrix,
-// held in LDS as [M1][T/2] float4 = two adjacent columns per 16-byte slot, so that one
-// thread transforms two columns with shared twiddles and b128 LDS accesses.
+// held in LDS as [M1][T/2] float4 slots; a slot is the pair-planar image
+// {re0, re1, im0, im1} of two adjacent columns (lds_fft.h), so one thread transforms two
+// columns with shared twiddles, packed arithmetic and b128 LDS accesses.
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ LdsLayout col_layout(const AsxDev &P)
 {
     LdsLayout L;
     L.ngroups = P.T >> 1;
     L.log_ngroups = P.logT - 1;
-    L.elem_stride = P.T;
-    L.group_stride = 2;
-    L.member_stride = 1;
+    L.elem_stride = P.T >> 1;
+    L.group_stride = 1;
     return L;
 }
 
@@ -49,10 +49,11 @@ __device__ __forceinline__ LdsLayout col_layout(const AsxDev &P)
 // Packs real samples as complex (z[j] = x[2j] + i x[2j+1]); zero padding and the periodic
 // extension of the source (embedded lengths) happen in the loads, never in HBM.
 template <int MAXR>
-__global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_fwd_cols(const AsxDev *__restrict__ Pp, const float *__restrict__ src,
-                                                                   const float *__restrict__ smp,
-                                                                   float2 *__restrict__ zxa,
-                                                                   float2 *__restrict__ zya)
+__global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_fwd_cols(const AsxDev *__restrict__ Pp,
+                                                                      const float *__restrict__ src,
+                                                                      const float *__restrict__ smp,
+                                                                      float2 *__restrict__ zxa,
+                                                                      float2 *__restrict__ zya)
 {
     const AsxDev &P = *Pp; // plan constants live in device memory: uniform scalar loads
     const int tile = blockIdx.x;
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_fwd_cols(const AsxDe
     for (int e = threadIdx.x; e < nelem4; e += blockDim.x) {
         const int cg = e & (H - 1), j1 = e >> logH;
         const int j2 = c0 + 2 * cg;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f); // (re0, im0, re1, im1) as it lies in memory
         if (j2 < M2) {
             const uint32_t i0 = 2u * ((uint32_t)j1 * (uint32_t)M2 + (uint32_t)j2);
             if (vec_in && i0 + 3u < valid && i0 + 3u < period) {
@@ -88,10 +89,10 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_fwd_cols(const AsxDe
                 v = make_float4(r[0], r[1], r[2], r[3]);
             }
         }
-        lds4[e] = v;
+        lds4[e] = make_float4(v.x, v.z, v.y, v.w); // pair-planar
     }
     __syncthreads();
-    lds_fft<MAXR, false, 2, true, true>(asx_lds, P.st1, col_layout(P), P.tw1);
+    lds_fft<MAXR, false, true>(lds4, P.st1, col_layout(P), P.tw1);
 
     // slot p1 holds frequency k1 = k1_of_pos1[p1] and stays in that slot in HBM; the
     // four-step twiddle w_M^(k1*j2) is applied by k_rows, where k1 is block-uniform.
@@ -102,10 +103,10 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_fwd_cols(const AsxDe
             const float4 v = lds4[e];
             float2 *o = out + (size_t)p1 * M2 + j2;
             if (even) {
-                *reinterpret_cast<float4 *>(o) = v;
+                *reinterpret_cast<float4 *>(o) = make_float4(v.x, v.z, v.y, v.w);
             } else {
-                o[0] = make_float2(v.x, v.y);
-                if (j2 + 1 < M2) o[1] = make_float2(v.z, v.w);
+                o[0] = make_float2(v.x, v.z);
+                if (j2 + 1 < M2) o[1] = make_float2(v.y, v.w);
             }
         }
     }
@@ -113,22 +114,23 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_fwd_cols(const AsxDe
 
 // ---------------------------------------------------------------------------
 // k_rows: grid (M1/2 + 1, npairs).  Block k1 handles spectrum rows k1 and m1 = M1 - k1
-// (the rows that hold each other's k <-> M-k partners).  LDS: A[M2], B[M2] float4 with
-// A[e] = {X_k1[e], Y_k1[e]}, B[e] = {X_m1[e], Y_m1[e]}: the two spectra of a row travel
-// together (one b128 access, shared twiddles).  Self-paired rows (k1 = 0, M1/2) use A only.
+// (the rows that hold each other's k <-> M-k partners).  LDS: A[M2], B[M2] float4 slots,
+// pair-planar over the two SPECTRA: A[e] = {Re X, Re Y, Im X, Im Y} of row k1, B of row m1.
+// After the spectral combine the same storage holds C[e] = {Re Ga, Re Gb, Im Ga, Im Gb},
+// the two rows of G, which the inverse transforms as one pair.  Self-paired rows
+// (k1 = 0, M1/2) use A only and carry zeros in the second member of C.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ void combine_pair(float2 ax, float2 bx, float2 ay, float2 by, float2 w,
-                                             float2 &Gk, float2 &Gm)
+__device__ __forceinline__ void combine_pair(Cx2 Za, Cx2 Zb, float2 w, float2 &Gk, float2 &Gm)
 {
-    // real-FFT untangling: E = (a + conj b)/2, O = -i (a - conj b)/2, X[k] = E + w O,
-    // X[M-k] = conj(E - w O)
-    const float2 Ex = make_float2(0.5f * (ax.x + bx.x), 0.5f * (ax.y - bx.y));
-    const float2 Ox = make_float2(0.5f * (ax.y + bx.y), -0.5f * (ax.x - bx.x));
-    const float2 Ey = make_float2(0.5f * (ay.x + by.x), 0.5f * (ay.y - by.y));
-    const float2 Oy = make_float2(0.5f * (ay.y + by.y), -0.5f * (ay.x - by.x));
-    const float2 wOx = cmul(w, Ox), wOy = cmul(w, Oy);
-    const float2 Xk = cadd(Ex, wOx), Xm = cconj(csub(Ex, wOx));
-    const float2 Yk = cadd(Ey, wOy), Ym = cconj(csub(Ey, wOy));
+    // members of Za/Zb: (X, Y).  Real-FFT untangling of both spectra at once:
+    // E = (a + conj b)/2, O = -i (a - conj b)/2, X[k] = E + w O, X[M-k] = conj(E - w O)
+    const Cx2 E = Cx2{ 0.5f * (Za.re + Zb.re), 0.5f * (Za.im - Zb.im) };
+    const Cx2 O = Cx2{ 0.5f * (Za.im + Zb.im), -0.5f * (Za.re - Zb.re) };
+    const Cx2 wO = mulw(O, w);
+    const Cx2 K = E + wO;                 // (X[k], Y[k])
+    const Cx2 Mm = E - wO;                // conj of (X[M-k], Y[M-k])
+    const float2 Xk = make_float2(K.re.x, K.im.x), Yk = make_float2(K.re.y, K.im.y);
+    const float2 Xm = make_float2(Mm.re.x, -Mm.im.x), Ym = make_float2(Mm.re.y, -Mm.im.y);
     // src/cross_correlation.c:232-233: arr1[i] *= conj(arr2[i])
     const float2 Pk = cmulc(Xk, Yk), Pm = cmulc(Xm, Ym);
     // inverse tangling: G[k] = (P[k] + conj P[M-k]) + i conj(w) (P[k] - conj P[M-k])
@@ -139,9 +141,10 @@ __device__ __forceinline__ void combine_pair(float2 ax, float2 bx, float2 ay, fl
 }
 
 template <int MAXR>
-__global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_rows(const AsxDev *__restrict__ Pp, const float2 *__restrict__ zxa,
-                                                               const float2 *__restrict__ zya,
-                                                               float2 *__restrict__ ga)
+__global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_rows(const AsxDev *__restrict__ Pp,
+                                                                  const float2 *__restrict__ zxa,
+                                                                  const float2 *__restrict__ zya,
+                                                                  float2 *__restrict__ ga)
 {
     const AsxDev &P = *Pp; // plan constants live in device memory: uniform scalar loads
     const int M1 = P.M1, M2 = P.M2;
@@ -151,12 +154,12 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_rows(const AsxDev *_
     const size_t pair = blockIdx.y;
     const int pa = P.pos1_of_k1[k1], pb = P.pos1_of_k1[m1];
     float4 *A4 = reinterpret_cast<float4 *>(asx_lds), *B4 = A4 + M2;
-    float2 *A2 = asx_lds, *B2 = asx_lds + 2 * M2; // .xy of slot e is A2[2e]
+    float *Cf = reinterpret_cast<float *>(asx_lds);
 
     // Four-step twiddle of row k1: w_M^(k1*j2) with j2 = t + blockDim*i factors into
     // w_M^(k1*t) (one two-level lookup per thread) times w_M^(k1*blockDim*i) (a handful per block).
     __shared__ float2 tw_step[2][ASX_ROW_STEPS];
-    const int nsteps = (M2 + (int)blockDim.x - 1) / (int)blockDim.x;
+    const int nsteps = (M2 + (int)blockDim.x - 1) / (int)blockDim.x; // <= ASX_ROW_STEPS (launcher)
     if ((int)threadIdx.x < 2 * nsteps) {
         const int which = (int)threadIdx.x >= nsteps;
         const int i = threadIdx.x - which * nsteps;
@@ -170,84 +173,92 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_rows(const AsxDev *_
 
     const float2 *gx = zxa + pair * (size_t)P.M, *gy = zya + pair * (size_t)P.M;
     for (int j2 = threadIdx.x, i = 0; j2 < M2; j2 += blockDim.x, i++) {
-        const float2 wa = cmul(twa, tw_step[0][i]);
-        const float2 x = cmul(gx[(size_t)pa * M2 + j2], wa), y = cmul(gy[(size_t)pa * M2 + j2], wa);
-        A4[j2] = make_float4(x.x, x.y, y.x, y.y);
+        const float2 x = gx[(size_t)pa * M2 + j2], y = gy[(size_t)pa * M2 + j2];
+        lds_put(A4 + j2, mulw(Cx2{ v2f{ x.x, y.x }, v2f{ x.y, y.y } }, cmul(twa, tw_step[0][i])));
         if (!self) {
-            const float2 wb = cmul(twb, tw_step[1][i]);
-            const float2 xb = cmul(gx[(size_t)pb * M2 + j2], wb), yb = cmul(gy[(size_t)pb * M2 + j2], wb);
-            B4[j2] = make_float4(xb.x, xb.y, yb.x, yb.y);
+            const float2 xb = gx[(size_t)pb * M2 + j2], yb = gy[(size_t)pb * M2 + j2];
+            lds_put(B4 + j2, mulw(Cx2{ v2f{ xb.x, yb.x }, v2f{ xb.y, yb.y } }, cmul(twb, tw_step[1][i])));
         }
     }
     __syncthreads();
     {
         LdsLayout L;
         L.ngroups = self ? 1 : 2; L.log_ngroups = 0;
-        L.elem_stride = 2; L.group_stride = 2 * M2; L.member_stride = 1;
-        lds_fft<MAXR, false, 2, true, false>(asx_lds, P.st2, L, P.tw2);
+        L.elem_stride = 1; L.group_stride = M2;
+        lds_fft<MAXR, false, false>(A4, P.st2, L, P.tw2);
     }
 
-    // ---- spectral combine, in place: G[k] -> A[.].xy, G[M-k] -> B[.].xy (or A for self rows) ----
+    // ---- spectral combine.  Every thread first computes its G values into registers (it
+    // reads slots other threads will overwrite), then, after a barrier, scatters them:
+    // G[k] -> C[sa] member 0, G[M-k] -> C[sb] member 1 (member 0 for self-paired rows).
     const float2 wA = tw_F(P, (uint32_t)k1); // w_F^k1, block-uniform
-    if (!self) {
-        for (int k2 = threadIdx.x; k2 < M2; k2 += blockDim.x) {
-            const int sa = P.pos2_of_k2[k2], sb = P.pos2_of_k2[M2 - 1 - k2];
-            const float2 w = cmul(wA, P.tw_b[k2]); // w_F^(k1 + M1*k2)
-            const float4 a = A4[sa], b = B4[sb];
-            float2 Gk, Gm;
-            combine_pair(make_float2(a.x, a.y), make_float2(b.x, b.y), make_float2(a.z, a.w),
-                         make_float2(b.z, b.w), w, Gk, Gm);
-            A2[2 * sa] = Gk;
-            B2[2 * sb] = Gm;
-        }
-    } else if (k1 == 0) {
-        for (int k2 = threadIdx.x; k2 <= M2 / 2; k2 += blockDim.x) {
+    float2 gk[ASX_ROW_STEPS], gm[ASX_ROW_STEPS];
+    int sa[ASX_ROW_STEPS], sb[ASX_ROW_STEPS]; // -1: nothing to write
+    static_for<0, ASX_ROW_STEPS>([&](auto I) __attribute__((always_inline)) {
+        constexpr int i = decltype(I)::value;
+        const int k2 = threadIdx.x + i * blockDim.x;
+        sa[i] = -1; sb[i] = -1;
+        gk[i] = make_float2(0.f, 0.f); gm[i] = make_float2(0.f, 0.f);
+        if (!self) {
+            if (k2 < M2) {
+                sa[i] = P.pos2_of_k2[k2]; sb[i] = P.pos2_of_k2[M2 - 1 - k2];
+                combine_pair(lds_get(A4 + sa[i]), lds_get(B4 + sb[i]), cmul(wA, P.tw_b[k2]), gk[i], gm[i]);
+            }
+        } else if (k1 == 0) {
             if (k2 == 0) {
                 // DC and Nyquist bins are real: X[0] = Re Z0 + Im Z0, X[M] = Re Z0 - Im Z0
-                const float4 z = A4[0];
-                const float P0 = (z.x + z.y) * (z.z + z.w);
-                const float PM = (z.x - z.y) * (z.z - z.w);
-                A2[0] = make_float2(P0 + PM, P0 - PM);
-            } else {
+                const Cx2 z = lds_get(A4);
+                const float P0 = (z.re.x + z.im.x) * (z.re.y + z.im.y);
+                const float PM = (z.re.x - z.im.x) * (z.re.y - z.im.y);
+                sa[i] = 0;
+                gk[i] = make_float2(P0 + PM, P0 - PM);
+            } else if (k2 <= M2 / 2) {
                 const int m2 = M2 - k2;
-                const int sa = P.pos2_of_k2[k2], sb = P.pos2_of_k2[m2];
-                const float4 a = A4[sa], b = A4[sb];
-                float2 Gk, Gm;
-                combine_pair(make_float2(a.x, a.y), make_float2(b.x, b.y), make_float2(a.z, a.w),
-                             make_float2(b.z, b.w), P.tw_b[k2], Gk, Gm);
-                A2[2 * sa] = Gk;
-                if (m2 != k2) A2[2 * sb] = Gm;
+                sa[i] = P.pos2_of_k2[k2];
+                const int s2 = P.pos2_of_k2[m2];
+                combine_pair(lds_get(A4 + sa[i]), lds_get(A4 + s2), P.tw_b[k2], gk[i], gm[i]);
+                if (m2 != k2) sb[i] = s2;
+            }
+        } else { // k1 == M1/2, M1 even
+            if (k2 < (M2 + 1) / 2) {
+                const int m2 = M2 - 1 - k2;
+                sa[i] = P.pos2_of_k2[k2];
+                const int s2 = P.pos2_of_k2[m2];
+                combine_pair(lds_get(A4 + sa[i]), lds_get(A4 + s2), cmul(wA, P.tw_b[k2]), gk[i], gm[i]);
+                if (m2 != k2) sb[i] = s2;
             }
         }
-    } else { // k1 == M1/2, M1 even
-        for (int k2 = threadIdx.x; k2 < (M2 + 1) / 2; k2 += blockDim.x) {
-            const int m2 = M2 - 1 - k2;
-            const int sa = P.pos2_of_k2[k2], sb = P.pos2_of_k2[m2];
-            const float2 w = cmul(wA, P.tw_b[k2]);
-            const float4 a = A4[sa], b = A4[sb];
-            float2 Gk, Gm;
-            combine_pair(make_float2(a.x, a.y), make_float2(b.x, b.y), make_float2(a.z, a.w),
-                         make_float2(b.z, b.w), w, Gk, Gm);
-            A2[2 * sa] = Gk;
-            if (m2 != k2) A2[2 * sb] = Gm;
+    });
+    __syncthreads();
+    static_for<0, ASX_ROW_STEPS>([&](auto I) __attribute__((always_inline)) {
+        constexpr int i = decltype(I)::value;
+        if (!self) {
+            if (sa[i] >= 0) {
+                Cf[4 * sa[i] + 0] = gk[i].x; Cf[4 * sa[i] + 2] = gk[i].y;
+                Cf[4 * sb[i] + 1] = gm[i].x; Cf[4 * sb[i] + 3] = gm[i].y;
+            }
+        } else {
+            if (sa[i] >= 0) A4[sa[i]] = make_float4(gk[i].x, 0.f, gk[i].y, 0.f);
+            if (sb[i] >= 0) A4[sb[i]] = make_float4(gm[i].x, 0.f, gm[i].y, 0.f);
         }
-    }
+    });
     __syncthreads();
 
-    // inverse row transforms of G (the .xy halves of A and B), digit-reversed in -> natural j2 out
+    // inverse row transforms of the G pair, digit-reversed in -> natural j2 out
     {
         LdsLayout L;
         L.ngroups = 1; L.log_ngroups = 0;
-        L.elem_stride = 2; L.group_stride = 0; L.member_stride = 2 * M2;
-        if (self) lds_fft<MAXR, true, 1, false, false>(asx_lds, P.st2, L, P.tw2);
-        else lds_fft<MAXR, true, 2, false, false>(asx_lds, P.st2, L, P.tw2);
+        L.elem_stride = 1; L.group_stride = 0;
+        lds_fft<MAXR, true, false>(A4, P.st2, L, P.tw2);
     }
 
-    // inverse four-step twiddle conj(w_M^(k1*j2)), same factors
+    // inverse four-step twiddle conj(w_M^(k1*j2)) / conj(w_M^(m1*j2)), one per member
     float2 *go = ga + pair * (size_t)P.M;
     for (int j2 = threadIdx.x, i = 0; j2 < M2; j2 += blockDim.x, i++) {
-        go[(size_t)pa * M2 + j2] = cmulc(A2[2 * j2], cmul(twa, tw_step[0][i]));
-        if (!self) go[(size_t)pb * M2 + j2] = cmulc(B2[2 * j2], cmul(twb, tw_step[1][i]));
+        const float2 wa = cmul(twa, tw_step[0][i]), wb = cmul(twb, tw_step[1][i]);
+        const Cx2 g = mul2c(lds_get(A4 + j2), Cx2{ v2f{ wa.x, wb.x }, v2f{ wa.y, wb.y } });
+        go[(size_t)pa * M2 + j2] = make_float2(g.re.x, g.im.x);
+        if (!self) go[(size_t)pb * M2 + j2] = make_float2(g.re.y, g.im.y);
     }
 }
 
@@ -368,11 +379,11 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_inv_cols(const AsxDe
                 v = make_float4(a.x, a.y, b.x, b.y);
             }
         }
-        lds4[e] = v;
+        lds4[e] = make_float4(v.x, v.z, v.y, v.w); // pair-planar
     }
     if (threadIdx.x == 0) ncand = 0;
     __syncthreads();
-    lds_fft<MAXR, true, 2, true, true>(asx_lds, P.st1, col_layout(P), P.tw1);
+    lds_fft<MAXR, true, true>(lds4, P.st1, col_layout(P), P.tw1);
 
     // running maximum per thread: a thread meets its lags in increasing order, so the strict
     // '>' keeps the earliest of equal keys, like the reference's sequential scan.
@@ -384,7 +395,7 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_inv_cols(const AsxDe
         if (j2 < M2) {
             const uint32_t i0 = 2u * ((uint32_t)j1 * (uint32_t)M2 + (uint32_t)j2);
             const float4 g = lds4[e];
-            const float val[4] = { g.x, g.y, g.z, g.w };
+            const float val[4] = { g.x, g.z, g.y, g.w }; // slot = {re0, re1, im0, im1}
 #pragma unroll
             for (int h = 0; h < 4; h++) {
                 const uint32_t idx = i0 + h;
@@ -410,7 +421,7 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_inv_cols(const AsxDe
         if (j2 < M2) {
             const uint32_t i0 = 2u * ((uint32_t)j1 * (uint32_t)M2 + (uint32_t)j2);
             const float4 g = lds4[e];
-            const float val[4] = { g.x, g.y, g.z, g.w };
+            const float val[4] = { g.x, g.z, g.y, g.w }; // slot = {re0, re1, im0, im1}
 #pragma unroll
             for (int h = 0; h < 4; h++) {
                 const uint32_t idx = i0 + h;
