@@ -151,6 +151,13 @@ static int plan_init(asx_plan *p, size_t N, size_t max_batch, const char *split)
         dev_alloc(p, &p->seg, g) ||
         dev_alloc(p, &p->psums, g * ASX_PEARSON_BLOCKS * 5))
         return -1;
+    d.stamps = nullptr;
+    if (getenv("ASX_STAMPS")) {
+        unsigned long long *st = nullptr;
+        if (dev_alloc(p, &st, g * (size_t)(h.M1 / 2 + 1) * 8)) return -1;
+        HIP_TRY(hipMemset(st, 0, g * (size_t)(h.M1 / 2 + 1) * 8 * sizeof(unsigned long long)));
+        d.stamps = st;
+    }
     {
         AsxDev *dcopy = nullptr;
         if (dev_alloc(p, &dcopy, 1)) return -1;
@@ -211,6 +218,16 @@ extern "C" size_t asx_plan_sample_len(const asx_plan *p) { return p ? p->host.N 
 extern "C" size_t asx_plan_fft_len(const asx_plan *p) { return p ? p->host.F : 0; }
 extern "C" size_t asx_plan_group(const asx_plan *p) { return p ? p->group : 0; }
 extern "C" size_t asx_plan_workspace_bytes(const asx_plan *p) { return p ? p->ws_bytes : 0; }
+// diagnostic: copy back the k_rows phase clocks of the last group (needs ASX_STAMPS env + -DASX_STAMPS build)
+extern "C" long asx_plan_debug_stamps(asx_plan *p, unsigned long long *out, size_t cap)
+{
+    if (!p || !p->dev.stamps) return -1;
+    size_t n = p->group * (size_t)(p->host.M1 / 2 + 1) * 8;
+    if (n > cap) n = cap;
+    if (hipMemcpy(out, p->dev.stamps, n * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return (long)n;
+}
+
 extern "C" int asx_plan_threads(const asx_plan *p, int *cols, int *rows)
 {
     if (!p) return -1;

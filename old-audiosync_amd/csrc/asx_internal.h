@@ -18,7 +18,8 @@
 #define ASX_TW_LO (1u << ASX_TW_LOG)
 #define ASX_THREADS 256                     // block size of the streaming kernels
 #define ASX_FFT_THREADS_MAX 512             // upper bound for the three transform kernels
-#define ASX_ROW_STEPS 8                     // max ceil(M2 / blockDim) in k_rows (register-staged combine)
+#define ASX_COL_LOADS 10                    // tile loads a thread keeps in flight in the column kernels
+#define ASX_ROW_STEPS 5                     // max ceil(M2 / blockDim) in k_rows (register-staged combine)
 #define ASX_PEARSON_BLOCKS 64               // partial-sum blocks per pair
 // Peak refinement: every lag whose float32 |r| is within ASX_REFINE_EPS (relative) of the
 // float32 maximum is re-evaluated exactly (float64 dot product of the inputs) and the
@@ -65,6 +66,7 @@ struct AsxDev {
     const int *pos1_of_k1; // k1 -> row slot
     const int *pos2_of_k2; // k2 -> slot inside a row after the forward row transform
     const AsxDev *self_dev; // device copy of this struct (what the kernels read)
+    unsigned long long *stamps; // diagnostic builds (-DASX_STAMPS) only: per-block phase clocks of k_rows
 };
 
 // Peak-search partial: order-preserving key in the high word, ~index in the low word,

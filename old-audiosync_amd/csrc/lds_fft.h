@@ -246,26 +246,6 @@ template <bool INV> struct Bfly<12, INV> : BflyC<3, 4, INV> {};
 template <bool INV> struct Bfly<15, INV> : BflyC<3, 5, INV> {};
 template <bool INV> struct Bfly<16, INV> : BflyC<4, 4, INV> {};
 
-// Stage twiddles w[u] = W^u, u = 1..R-1, W = tw[tj]: table reads at u = 1 and 4
-// (u*tj < n always holds), the rest by products of depth <= 3.
-template <int R> __device__ __forceinline__ void stage_twiddles(const float2 *__restrict__ tw, int tj, float2 (&w)[R])
-{
-    w[0] = make_float2(1.f, 0.f);
-    if constexpr (R >= 2) w[1] = tw[tj];
-    static_for<2, R>([&](auto U) __attribute__((always_inline)) {
-        constexpr int u = decltype(U)::value;
-        if constexpr (u == 4) {
-            w[u] = tw[4 * tj];
-        } else if constexpr (u < 4) {
-            w[u] = cmul(w[u - 1], w[1]);
-        } else {
-            constexpr int lo = u % 4, hi = u - lo;
-            if constexpr (lo == 0) w[u] = cmul(w[u - 4], w[4]);
-            else w[u] = cmul(w[hi], w[lo]);
-        }
-    });
-}
-
 // ---------------------------------------------------------------------------
 // One stage.  The LDS image is an array of float4 slots; slot (g, e) = element e of the
 // transform PAIR g sits at lds4[g*group_stride + e*elem_stride].  A work item is one
@@ -280,9 +260,58 @@ struct LdsLayout {
     int group_stride;
 };
 
+// Twiddle prefetch: the two table reads (W^1, W^4) a thread needs for its FIRST work item of a
+// stage depend only on (stage, threadIdx), not on data, so they are issued before the barrier
+// that ends the previous stage (or before the tile load) and ride in registers across it;
+// the L2 latency of the table read then overlaps the previous stage instead of stalling this one.
+struct TwPre {
+    float2 w1, w4;
+};
+
+template <bool GFAST>
+__device__ __forceinline__ TwPre tw_prefetch(const AsxStages &st, int i, const LdsLayout &L,
+                                             const float2 *__restrict__ tw)
+{
+    TwPre pre;
+    pre.w1 = make_float2(1.f, 0.f);
+    pre.w4 = make_float2(1.f, 0.f);
+    if (i < 0 || i >= st.nstages) return pre;
+    const int q = st.q[i], nbf = st.nbf[i];
+    const int w = threadIdx.x;
+    if (q == 1 || w >= L.ngroups * nbf) return pre;
+    int bf;
+    if (GFAST) bf = w >> L.log_ngroups;
+    else (void)div_exact(w, nbf, st.inv_nbf[i], bf);
+    int j;
+    (void)div_exact(bf, q, st.inv_q[i], j);
+    const int tj = j * st.twmul[i];
+    pre.w1 = tw[tj];
+    if (st.radix[i] > 4) pre.w4 = tw[4 * tj];
+    return pre;
+}
+
+// Stage twiddles from (W^1, W^4): products of depth <= 3
+template <int R> __device__ __forceinline__ void stage_twiddles_from(float2 w1, float2 w4, float2 (&w)[R])
+{
+    w[0] = make_float2(1.f, 0.f);
+    if constexpr (R >= 2) w[1] = w1;
+    static_for<2, R>([&](auto U) __attribute__((always_inline)) {
+        constexpr int u = decltype(U)::value;
+        if constexpr (u == 4) {
+            w[u] = w4;
+        } else if constexpr (u < 4) {
+            w[u] = cmul(w[u - 1], w[1]);
+        } else {
+            constexpr int lo = u % 4, hi = u - lo;
+            if constexpr (lo == 0) w[u] = cmul(w[u - 4], w[4]);
+            else w[u] = cmul(w[hi], w[lo]);
+        }
+    });
+}
+
 template <int R, bool INV, bool GFAST, bool UNIT_TW>
 __device__ __forceinline__ void lds_stage(float4 *lds, const AsxStages &st, int i, const LdsLayout &L,
-                                          const float2 *__restrict__ tw)
+                                          const float2 *__restrict__ tw, TwPre pre)
 {
     const int ns = st.ns[i], q = st.q[i], nbf = st.nbf[i], twmul = st.twmul[i];
     const float inv_q = st.inv_q[i], inv_nbf = st.inv_nbf[i];
@@ -304,8 +333,14 @@ __device__ __forceinline__ void lds_stage(float4 *lds, const AsxStages &st, int 
         if constexpr (UNIT_TW) {
             Bfly<R, INV>::run(v);
         } else {
+            float2 w1 = pre.w1, w4 = pre.w4;
+            if (w != (int)threadIdx.x) { // later work items of this thread: read the table now
+                const int tj = j * twmul;
+                w1 = tw[tj];
+                if constexpr (R > 4) w4 = tw[4 * tj];
+            }
             float2 tww[R];
-            stage_twiddles<R>(tw, j * twmul, tww);
+            stage_twiddles_from<R>(w1, w4, tww);
             if constexpr (!INV) {
                 Bfly<R, false>::run(v);
                 static_for<1, R>([&](auto U) __attribute__((always_inline)) { v[U] = mulw(v[U], tww[U]); });
@@ -320,22 +355,22 @@ __device__ __forceinline__ void lds_stage(float4 *lds, const AsxStages &st, int 
 
 template <int R, bool INV, bool GFAST>
 __device__ __forceinline__ void lds_stage_r(float4 *lds, const AsxStages &st, int i, const LdsLayout &L,
-                                            const float2 *__restrict__ tw)
+                                            const float2 *__restrict__ tw, TwPre pre)
 {
     if (st.q[i] == 1) // wave-uniform
-        lds_stage<R, INV, GFAST, true>(lds, st, i, L, tw);
+        lds_stage<R, INV, GFAST, true>(lds, st, i, L, tw, pre);
     else
-        lds_stage<R, INV, GFAST, false>(lds, st, i, L, tw);
+        lds_stage<R, INV, GFAST, false>(lds, st, i, L, tw, pre);
 }
 
 // MAXR: largest radix this kernel variant carries code for.  Register allocation is per
 // kernel, so a variant without the radix-15/16 bodies keeps the occupancy of the small ones.
 template <int MAXR, bool INV, bool GFAST>
 __device__ __forceinline__ void lds_stage_any(float4 *lds, const AsxStages &st, int i, const LdsLayout &L,
-                                              const float2 *__restrict__ tw)
+                                              const float2 *__restrict__ tw, TwPre pre)
 {
 #define ASX_STAGE_CASE(R) \
-    case R: if constexpr (R <= MAXR) lds_stage_r<R, INV, GFAST>(lds, st, i, L, tw); break;
+    case R: if constexpr (R <= MAXR) lds_stage_r<R, INV, GFAST>(lds, st, i, L, tw, pre); break;
     switch (st.radix[i]) { // wave-uniform
         ASX_STAGE_CASE(16)
         ASX_STAGE_CASE(15)
@@ -347,25 +382,31 @@ __device__ __forceinline__ void lds_stage_any(float4 *lds, const AsxStages &st, 
         ASX_STAGE_CASE(5)
         ASX_STAGE_CASE(4)
         ASX_STAGE_CASE(3)
-    default: lds_stage_r<2, INV, GFAST>(lds, st, i, L, tw); break;
+    default: lds_stage_r<2, INV, GFAST>(lds, st, i, L, tw, pre); break;
     }
 #undef ASX_STAGE_CASE
 }
 
-// Whole transform.  Caller has filled LDS and called __syncthreads(); on return
-// all lanes see the result (the routine ends with a barrier).
+// Whole transform.  `pre` = tw_prefetch() of the first stage to run (stage 0 forward,
+// stage nstages-1 inverse), issued by the caller before it waited for the tile.  Caller has
+// filled LDS and called __syncthreads(); on return all lanes see the result (the routine
+// ends with a barrier).
 template <int MAXR, bool INV, bool GFAST>
 __device__ __forceinline__ void lds_fft(float4 *lds, const AsxStages &st, const LdsLayout &L,
-                                        const float2 *__restrict__ tw)
+                                        const float2 *__restrict__ tw, TwPre pre)
 {
     if (!INV) {
         for (int i = 0; i < st.nstages; i++) {
-            lds_stage_any<MAXR, false, GFAST>(lds, st, i, L, tw);
+            const TwPre next = tw_prefetch<GFAST>(st, i + 1, L, tw);
+            lds_stage_any<MAXR, false, GFAST>(lds, st, i, L, tw, pre);
+            pre = next;
             __syncthreads();
         }
     } else {
         for (int i = st.nstages - 1; i >= 0; i--) {
-            lds_stage_any<MAXR, true, GFAST>(lds, st, i, L, tw);
+            const TwPre next = tw_prefetch<GFAST>(st, i - 1, L, tw);
+            lds_stage_any<MAXR, true, GFAST>(lds, st, i, L, tw, pre);
+            pre = next;
             __syncthreads();
         }
     }

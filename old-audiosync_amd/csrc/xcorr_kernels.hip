@@ -19,6 +19,22 @@
 
 #include <math.h>
 
+// Diagnostic phase clocks (never in a shipped build; -DASX_STAMPS): lane 0 of every k_rows block
+// records s_memtime at phase boundaries into a buffer nothing else reads.
+#ifdef ASX_STAMPS
+#define ASX_STAMP(slot)                                                                              \
+    do {                                                                                             \
+        if (P.stamps && threadIdx.x == 0)                                                            \
+            P.stamps[(size_t)task * 8 + (slot)] = clock64();        \
+    } while (0)
+#else
+#define ASX_STAMP(slot) do {} while (0)
+#endif
+
+#ifndef ASX_ROWS_MIN_WAVES
+#define ASX_ROWS_MIN_WAVES 3   // k_rows needs ~140 VGPRs with radix 12: three waves per SIMD without spills
+#endif
+
 extern __shared__ __attribute__((aligned(16))) float2 asx_lds[];
 
 // w_F^p for p < F from the two-level table (one complex multiply, ~1.5e-7 accurate).
@@ -71,28 +87,39 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_fwd_cols(const AsxDe
     float4 *lds4 = reinterpret_cast<float4 *>(asx_lds);
 
     const int nelem4 = M1 << logH;
-    for (int e = threadIdx.x; e < nelem4; e += blockDim.x) {
-        const int cg = e & (H - 1), j1 = e >> logH;
-        const int j2 = c0 + 2 * cg;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f); // (re0, im0, re1, im1) as it lies in memory
-        if (j2 < M2) {
-            const uint32_t i0 = 2u * ((uint32_t)j1 * (uint32_t)M2 + (uint32_t)j2);
-            if (vec_in && i0 + 3u < valid && i0 + 3u < period) {
-                v = *reinterpret_cast<const float4 *>(in + i0);
-            } else {
-                float r[4] = { 0.f, 0.f, 0.f, 0.f };
+    const LdsLayout Lc = col_layout(P);
+    const TwPre pre = tw_prefetch<true>(P.st1, 0, Lc, P.tw1);
+    // all of a thread's tile loads are issued before the first is consumed (ASX_COL_LOADS per
+    // round): a rolled loop would pay the HBM latency once per iteration
+    for (int e0 = threadIdx.x; e0 < nelem4; e0 += ASX_COL_LOADS * blockDim.x) {
+        float4 v[ASX_COL_LOADS];
+        static_for<0, ASX_COL_LOADS>([&](auto I) __attribute__((always_inline)) {
+            const int e = e0 + decltype(I)::value * blockDim.x;
+            const int cg = e & (H - 1), j1 = e >> logH;
+            const int j2 = c0 + 2 * cg;
+            v[I] = make_float4(0.f, 0.f, 0.f, 0.f); // (re0, im0, re1, im1) as it lies in memory
+            if (e < nelem4 && j2 < M2) {
+                const uint32_t i0 = 2u * ((uint32_t)j1 * (uint32_t)M2 + (uint32_t)j2);
+                if (vec_in && i0 + 3u < valid && i0 + 3u < period) {
+                    v[I] = *reinterpret_cast<const float4 *>(in + i0);
+                } else {
+                    float r[4] = { 0.f, 0.f, 0.f, 0.f };
 #pragma unroll
-                for (int h = 0; h < 4; h++) {
-                    const uint32_t idx = i0 + h;
-                    if (j2 + (h >> 1) < M2 && idx < valid) r[h] = in[idx < period ? idx : idx - period];
+                    for (int h = 0; h < 4; h++) {
+                        const uint32_t idx = i0 + h;
+                        if (j2 + (h >> 1) < M2 && idx < valid) r[h] = in[idx < period ? idx : idx - period];
+                    }
+                    v[I] = make_float4(r[0], r[1], r[2], r[3]);
                 }
-                v = make_float4(r[0], r[1], r[2], r[3]);
             }
-        }
-        lds4[e] = make_float4(v.x, v.z, v.y, v.w); // pair-planar
+        });
+        static_for<0, ASX_COL_LOADS>([&](auto I) __attribute__((always_inline)) {
+            const int e = e0 + decltype(I)::value * blockDim.x;
+            if (e < nelem4) lds4[e] = make_float4(v[I].x, v[I].z, v[I].y, v[I].w); // pair-planar
+        });
     }
     __syncthreads();
-    lds_fft<MAXR, false, true>(lds4, P.st1, col_layout(P), P.tw1);
+    lds_fft<MAXR, false, true>(lds4, P.st1, Lc, P.tw1, pre);
 
     // slot p1 holds frequency k1 = k1_of_pos1[p1] and stays in that slot in HBM; the
     // four-step twiddle w_M^(k1*j2) is applied by k_rows, where k1 is block-uniform.
@@ -140,125 +167,166 @@ __device__ __forceinline__ void combine_pair(Cx2 Za, Cx2 Zb, float2 w, float2 &G
     Gm = make_float2(S.x + V.y, V.x - S.y);
 }
 
+// Row loads of one task, all issued before the first is consumed.  (Issuing them one task
+// AHEAD in a persistent block was tried: +50 live VGPRs pushed k_rows to 221 registers = two
+// waves per SIMD, and the kernel got 1.6x slower; see DESIGN.md "what did not work".)
+struct RowRegs {
+    float2 xa[ASX_ROW_STEPS], ya[ASX_ROW_STEPS], xb[ASX_ROW_STEPS], yb[ASX_ROW_STEPS];
+};
+
 template <int MAXR>
-__global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_rows(const AsxDev *__restrict__ Pp,
+__global__ __launch_bounds__(ASX_FFT_THREADS_MAX, ASX_ROWS_MIN_WAVES) void k_rows(const AsxDev *__restrict__ Pp,
                                                                   const float2 *__restrict__ zxa,
                                                                   const float2 *__restrict__ zya,
-                                                                  float2 *__restrict__ ga)
+                                                                  float2 *__restrict__ ga, int npairs)
 {
     const AsxDev &P = *Pp; // plan constants live in device memory: uniform scalar loads
     const int M1 = P.M1, M2 = P.M2;
-    const int k1 = blockIdx.x;
-    const int m1 = (M1 - k1) % M1;
-    const bool self = (k1 == m1);
-    const size_t pair = blockIdx.y;
-    const int pa = P.pos1_of_k1[k1], pb = P.pos1_of_k1[m1];
+    const int nrows = M1 / 2 + 1;
+    (void)npairs;                            // task = (pair, k1) = blockIdx.x
     float4 *A4 = reinterpret_cast<float4 *>(asx_lds), *B4 = A4 + M2;
     float *Cf = reinterpret_cast<float *>(asx_lds);
-
-    // Four-step twiddle of row k1: w_M^(k1*j2) with j2 = t + blockDim*i factors into
-    // w_M^(k1*t) (one two-level lookup per thread) times w_M^(k1*blockDim*i) (a handful per block).
     __shared__ float2 tw_step[2][ASX_ROW_STEPS];
-    const int nsteps = (M2 + (int)blockDim.x - 1) / (int)blockDim.x; // <= ASX_ROW_STEPS (launcher)
-    if ((int)threadIdx.x < 2 * nsteps) {
-        const int which = (int)threadIdx.x >= nsteps;
-        const int i = threadIdx.x - which * nsteps;
-        const uint32_t row = which ? (uint32_t)m1 : (uint32_t)k1;
-        tw_step[which][i] = tw_F(P, 2u * row * (uint32_t)(i * (int)blockDim.x));
-    }
-    const uint32_t tcol = threadIdx.x < (unsigned)M2 ? threadIdx.x : 0u;
-    const float2 twa = tw_F(P, 2u * (uint32_t)k1 * tcol);
-    const float2 twb = tw_F(P, 2u * (uint32_t)m1 * tcol);
-    __syncthreads();
 
-    const float2 *gx = zxa + pair * (size_t)P.M, *gy = zya + pair * (size_t)P.M;
-    for (int j2 = threadIdx.x, i = 0; j2 < M2; j2 += blockDim.x, i++) {
-        const float2 x = gx[(size_t)pa * M2 + j2], y = gy[(size_t)pa * M2 + j2];
-        lds_put(A4 + j2, mulw(Cx2{ v2f{ x.x, y.x }, v2f{ x.y, y.y } }, cmul(twa, tw_step[0][i])));
-        if (!self) {
-            const float2 xb = gx[(size_t)pb * M2 + j2], yb = gy[(size_t)pb * M2 + j2];
-            lds_put(B4 + j2, mulw(Cx2{ v2f{ xb.x, yb.x }, v2f{ xb.y, yb.y } }, cmul(twb, tw_step[1][i])));
-        }
-    }
-    __syncthreads();
+    // one task per block (grid = ntasks)
+    const int task = blockIdx.x;
     {
-        LdsLayout L;
-        L.ngroups = self ? 1 : 2; L.log_ngroups = 0;
-        L.elem_stride = 1; L.group_stride = M2;
-        lds_fft<MAXR, false, false>(A4, P.st2, L, P.tw2);
-    }
+        const int pair = task / nrows;
+        const int k1 = task - pair * nrows;
+        const int m1 = (M1 - k1) % M1;
+        const bool self = (k1 == m1);
+        ASX_STAMP(0);
+        const int pa = P.pos1_of_k1[k1], pb = P.pos1_of_k1[m1];
 
-    // ---- spectral combine.  Every thread first computes its G values into registers (it
-    // reads slots other threads will overwrite), then, after a barrier, scatters them:
-    // G[k] -> C[sa] member 0, G[M-k] -> C[sb] member 1 (member 0 for self-paired rows).
-    const float2 wA = tw_F(P, (uint32_t)k1); // w_F^k1, block-uniform
-    float2 gk[ASX_ROW_STEPS], gm[ASX_ROW_STEPS];
-    int sa[ASX_ROW_STEPS], sb[ASX_ROW_STEPS]; // -1: nothing to write
-    static_for<0, ASX_ROW_STEPS>([&](auto I) __attribute__((always_inline)) {
-        constexpr int i = decltype(I)::value;
-        const int k2 = threadIdx.x + i * blockDim.x;
-        sa[i] = -1; sb[i] = -1;
-        gk[i] = make_float2(0.f, 0.f); gm[i] = make_float2(0.f, 0.f);
-        if (!self) {
-            if (k2 < M2) {
-                sa[i] = P.pos2_of_k2[k2]; sb[i] = P.pos2_of_k2[M2 - 1 - k2];
-                combine_pair(lds_get(A4 + sa[i]), lds_get(B4 + sb[i]), cmul(wA, P.tw_b[k2]), gk[i], gm[i]);
-            }
-        } else if (k1 == 0) {
-            if (k2 == 0) {
-                // DC and Nyquist bins are real: X[0] = Re Z0 + Im Z0, X[M] = Re Z0 - Im Z0
-                const Cx2 z = lds_get(A4);
-                const float P0 = (z.re.x + z.im.x) * (z.re.y + z.im.y);
-                const float PM = (z.re.x - z.im.x) * (z.re.y - z.im.y);
-                sa[i] = 0;
-                gk[i] = make_float2(P0 + PM, P0 - PM);
-            } else if (k2 <= M2 / 2) {
-                const int m2 = M2 - k2;
-                sa[i] = P.pos2_of_k2[k2];
-                const int s2 = P.pos2_of_k2[m2];
-                combine_pair(lds_get(A4 + sa[i]), lds_get(A4 + s2), P.tw_b[k2], gk[i], gm[i]);
-                if (m2 != k2) sb[i] = s2;
-            }
-        } else { // k1 == M1/2, M1 even
-            if (k2 < (M2 + 1) / 2) {
-                const int m2 = M2 - 1 - k2;
-                sa[i] = P.pos2_of_k2[k2];
-                const int s2 = P.pos2_of_k2[m2];
-                combine_pair(lds_get(A4 + sa[i]), lds_get(A4 + s2), cmul(wA, P.tw_b[k2]), gk[i], gm[i]);
-                if (m2 != k2) sb[i] = s2;
-            }
+        LdsLayout Lf;
+        Lf.ngroups = self ? 1 : 2; Lf.log_ngroups = 0;
+        Lf.elem_stride = 1; Lf.group_stride = M2;
+        LdsLayout Li;
+        Li.ngroups = 1; Li.log_ngroups = 0;
+        Li.elem_stride = 1; Li.group_stride = 0;
+        // every row load of the thread is issued first; the twiddle lookups below overlap them
+        RowRegs L;
+        {
+            const float2 *gx = zxa + (size_t)pair * P.M, *gy = zya + (size_t)pair * P.M;
+            static_for<0, ASX_ROW_STEPS>([&](auto I) __attribute__((always_inline)) {
+                const int j2 = threadIdx.x + decltype(I)::value * blockDim.x;
+                L.xa[I] = L.ya[I] = L.xb[I] = L.yb[I] = make_float2(0.f, 0.f);
+                if (j2 < M2) {
+                    L.xa[I] = gx[(size_t)pa * M2 + j2];
+                    L.ya[I] = gy[(size_t)pa * M2 + j2];
+                    if (!self) {
+                        L.xb[I] = gx[(size_t)pb * M2 + j2];
+                        L.yb[I] = gy[(size_t)pb * M2 + j2];
+                    }
+                }
+            });
         }
-    });
-    __syncthreads();
-    static_for<0, ASX_ROW_STEPS>([&](auto I) __attribute__((always_inline)) {
-        constexpr int i = decltype(I)::value;
-        if (!self) {
-            if (sa[i] >= 0) {
-                Cf[4 * sa[i] + 0] = gk[i].x; Cf[4 * sa[i] + 2] = gk[i].y;
-                Cf[4 * sb[i] + 1] = gm[i].x; Cf[4 * sb[i] + 3] = gm[i].y;
-            }
-        } else {
-            if (sa[i] >= 0) A4[sa[i]] = make_float4(gk[i].x, 0.f, gk[i].y, 0.f);
-            if (sb[i] >= 0) A4[sb[i]] = make_float4(gm[i].x, 0.f, gm[i].y, 0.f);
+        const TwPre pre_f = tw_prefetch<false>(P.st2, 0, Lf, P.tw2);
+
+        // Four-step twiddle of row k1: w_M^(k1*j2) with j2 = t + blockDim*i factors into
+        // w_M^(k1*t) (one two-level lookup per thread) times w_M^(k1*blockDim*i) (a handful per block).
+        const int nsteps = (M2 + (int)blockDim.x - 1) / (int)blockDim.x; // <= ASX_ROW_STEPS (launcher)
+        if ((int)threadIdx.x < 2 * nsteps) {
+            const int which = (int)threadIdx.x >= nsteps;
+            const int i = threadIdx.x - which * nsteps;
+            const uint32_t row = which ? (uint32_t)m1 : (uint32_t)k1;
+            tw_step[which][i] = tw_F(P, 2u * row * (uint32_t)(i * (int)blockDim.x));
         }
-    });
-    __syncthreads();
+        const uint32_t tcol = threadIdx.x < (unsigned)M2 ? threadIdx.x : 0u;
+        {
+            const float2 twa = tw_F(P, 2u * (uint32_t)k1 * tcol);
+            const float2 twb = tw_F(P, 2u * (uint32_t)m1 * tcol);
+            __syncthreads();
+            static_for<0, ASX_ROW_STEPS>([&](auto I) __attribute__((always_inline)) {
+                constexpr int i = decltype(I)::value;
+                const int j2 = threadIdx.x + i * blockDim.x;
+                if (j2 < M2) {
+                    lds_put(A4 + j2, mulw(Cx2{ v2f{ L.xa[I].x, L.ya[I].x }, v2f{ L.xa[I].y, L.ya[I].y } },
+                                          cmul(twa, tw_step[0][i])));
+                    if (!self)
+                        lds_put(B4 + j2, mulw(Cx2{ v2f{ L.xb[I].x, L.yb[I].x }, v2f{ L.xb[I].y, L.yb[I].y } },
+                                              cmul(twb, tw_step[1][i])));
+                }
+            });
+        }
+        __syncthreads();
+        ASX_STAMP(1);
+        lds_fft<MAXR, false, false>(A4, P.st2, Lf, P.tw2, pre_f);
+        ASX_STAMP(2);
 
-    // inverse row transforms of the G pair, digit-reversed in -> natural j2 out
-    {
-        LdsLayout L;
-        L.ngroups = 1; L.log_ngroups = 0;
-        L.elem_stride = 1; L.group_stride = 0;
-        lds_fft<MAXR, true, false>(A4, P.st2, L, P.tw2);
-    }
+        // ---- spectral combine.  Every thread first computes its G values into registers (it
+        // reads slots other threads will overwrite), then, after a barrier, scatters them:
+        // G[k] -> C[sa] member 0, G[M-k] -> C[sb] member 1 (member 0 for self-paired rows).
+        const float2 wA = tw_F(P, (uint32_t)k1); // w_F^k1, block-uniform
+        float2 gk[ASX_ROW_STEPS], gm[ASX_ROW_STEPS];
+        int sa[ASX_ROW_STEPS], sb[ASX_ROW_STEPS]; // -1: nothing to write
+        static_for<0, ASX_ROW_STEPS>([&](auto I) __attribute__((always_inline)) {
+            constexpr int i = decltype(I)::value;
+            const int k2 = threadIdx.x + i * blockDim.x;
+            sa[i] = -1; sb[i] = -1;
+            gk[i] = make_float2(0.f, 0.f); gm[i] = make_float2(0.f, 0.f);
+            if (!self) {
+                if (k2 < M2) {
+                    sa[i] = P.pos2_of_k2[k2]; sb[i] = P.pos2_of_k2[M2 - 1 - k2];
+                    combine_pair(lds_get(A4 + sa[i]), lds_get(B4 + sb[i]), cmul(wA, P.tw_b[k2]), gk[i], gm[i]);
+                }
+            } else if (k1 == 0) {
+                if (k2 == 0) {
+                    // DC and Nyquist bins are real: X[0] = Re Z0 + Im Z0, X[M] = Re Z0 - Im Z0
+                    const Cx2 z = lds_get(A4);
+                    const float P0 = (z.re.x + z.im.x) * (z.re.y + z.im.y);
+                    const float PM = (z.re.x - z.im.x) * (z.re.y - z.im.y);
+                    sa[i] = 0;
+                    gk[i] = make_float2(P0 + PM, P0 - PM);
+                } else if (k2 <= M2 / 2) {
+                    const int m2 = M2 - k2;
+                    sa[i] = P.pos2_of_k2[k2];
+                    const int s2 = P.pos2_of_k2[m2];
+                    combine_pair(lds_get(A4 + sa[i]), lds_get(A4 + s2), P.tw_b[k2], gk[i], gm[i]);
+                    if (m2 != k2) sb[i] = s2;
+                }
+            } else { // k1 == M1/2, M1 even
+                if (k2 < (M2 + 1) / 2) {
+                    const int m2 = M2 - 1 - k2;
+                    sa[i] = P.pos2_of_k2[k2];
+                    const int s2 = P.pos2_of_k2[m2];
+                    combine_pair(lds_get(A4 + sa[i]), lds_get(A4 + s2), cmul(wA, P.tw_b[k2]), gk[i], gm[i]);
+                    if (m2 != k2) sb[i] = s2;
+                }
+            }
+        });
+        const TwPre pre_i = tw_prefetch<false>(P.st2, P.st2.nstages - 1, Li, P.tw2);
+        __syncthreads();
+        static_for<0, ASX_ROW_STEPS>([&](auto I) __attribute__((always_inline)) {
+            constexpr int i = decltype(I)::value;
+            if (!self) {
+                if (sa[i] >= 0) {
+                    Cf[4 * sa[i] + 0] = gk[i].x; Cf[4 * sa[i] + 2] = gk[i].y;
+                    Cf[4 * sb[i] + 1] = gm[i].x; Cf[4 * sb[i] + 3] = gm[i].y;
+                }
+            } else {
+                if (sa[i] >= 0) A4[sa[i]] = make_float4(gk[i].x, 0.f, gk[i].y, 0.f);
+                if (sb[i] >= 0) A4[sb[i]] = make_float4(gm[i].x, 0.f, gm[i].y, 0.f);
+            }
+        });
+        __syncthreads();
 
-    // inverse four-step twiddle conj(w_M^(k1*j2)) / conj(w_M^(m1*j2)), one per member
-    float2 *go = ga + pair * (size_t)P.M;
-    for (int j2 = threadIdx.x, i = 0; j2 < M2; j2 += blockDim.x, i++) {
-        const float2 wa = cmul(twa, tw_step[0][i]), wb = cmul(twb, tw_step[1][i]);
-        const Cx2 g = mul2c(lds_get(A4 + j2), Cx2{ v2f{ wa.x, wb.x }, v2f{ wa.y, wb.y } });
-        go[(size_t)pa * M2 + j2] = make_float2(g.re.x, g.im.x);
-        if (!self) go[(size_t)pb * M2 + j2] = make_float2(g.re.y, g.im.y);
+        ASX_STAMP(3);
+        // inverse row transforms of the G pair, digit-reversed in -> natural j2 out
+        lds_fft<MAXR, true, false>(A4, P.st2, Li, P.tw2, pre_i);
+        ASX_STAMP(4);
+
+        // inverse four-step twiddle conj(w_M^(k1*j2)) / conj(w_M^(m1*j2)), one per member
+        float2 *go = ga + (size_t)pair * P.M;
+        const float2 twa = tw_F(P, 2u * (uint32_t)k1 * tcol); // looked up again: cheaper than 4 live VGPRs
+        const float2 twb = tw_F(P, 2u * (uint32_t)m1 * tcol);
+        for (int j2 = threadIdx.x, i = 0; j2 < M2; j2 += blockDim.x, i++) {
+            const float2 wa = cmul(twa, tw_step[0][i]), wb = cmul(twb, tw_step[1][i]);
+            const Cx2 g = mul2c(lds_get(A4 + j2), Cx2{ v2f{ wa.x, wb.x }, v2f{ wa.y, wb.y } });
+            go[(size_t)pa * M2 + j2] = make_float2(g.re.x, g.im.x);
+            if (!self) go[(size_t)pb * M2 + j2] = make_float2(g.re.y, g.im.y);
+        }
+        ASX_STAMP(5);
     }
 }
 
@@ -365,25 +433,34 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_inv_cols(const AsxDe
     float4 *lds4 = reinterpret_cast<float4 *>(asx_lds);
 
     const int nelem4 = M1 << logH;
-    for (int e = threadIdx.x; e < nelem4; e += blockDim.x) {
-        const int cg = e & (H - 1), p1 = e >> logH;
-        const int j2 = c0 + 2 * cg;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (j2 < M2) {
-            const float2 *g = in + (size_t)p1 * M2 + j2;
-            if (even) {
-                v = *reinterpret_cast<const float4 *>(g);
-            } else {
-                const float2 a = g[0];
-                const float2 b = (j2 + 1 < M2) ? g[1] : make_float2(0.f, 0.f);
-                v = make_float4(a.x, a.y, b.x, b.y);
+    const LdsLayout Lc = col_layout(P);
+    const TwPre pre = tw_prefetch<true>(P.st1, P.st1.nstages - 1, Lc, P.tw1);
+    for (int e0 = threadIdx.x; e0 < nelem4; e0 += ASX_COL_LOADS * blockDim.x) {
+        float4 v[ASX_COL_LOADS];
+        static_for<0, ASX_COL_LOADS>([&](auto I) __attribute__((always_inline)) {
+            const int e = e0 + decltype(I)::value * blockDim.x;
+            const int cg = e & (H - 1), p1 = e >> logH;
+            const int j2 = c0 + 2 * cg;
+            v[I] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < nelem4 && j2 < M2) {
+                const float2 *g = in + (size_t)p1 * M2 + j2;
+                if (even) {
+                    v[I] = *reinterpret_cast<const float4 *>(g);
+                } else {
+                    const float2 a = g[0];
+                    const float2 b = (j2 + 1 < M2) ? g[1] : make_float2(0.f, 0.f);
+                    v[I] = make_float4(a.x, a.y, b.x, b.y);
+                }
             }
-        }
-        lds4[e] = make_float4(v.x, v.z, v.y, v.w); // pair-planar
+        });
+        static_for<0, ASX_COL_LOADS>([&](auto I) __attribute__((always_inline)) {
+            const int e = e0 + decltype(I)::value * blockDim.x;
+            if (e < nelem4) lds4[e] = make_float4(v[I].x, v[I].z, v[I].y, v[I].w); // pair-planar
+        });
     }
     if (threadIdx.x == 0) ncand = 0;
     __syncthreads();
-    lds_fft<MAXR, true, true>(lds4, P.st1, col_layout(P), P.tw1);
+    lds_fft<MAXR, true, true>(lds4, P.st1, Lc, P.tw1, pre);
 
     // running maximum per thread: a thread meets its lags in increasing order, so the strict
     // '>' keeps the earliest of equal keys, like the reference's sequential scan.
@@ -731,6 +808,14 @@ int asx_pick_threads(const AsxStages &st, int groups, int min_threads, size_t ld
     return best;
 }
 
+static int asx_cu_count()
+{
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) return 256;
+    return n;
+}
+
 static int max_radix(const AsxStages &st)
 {
     int m = 2;
@@ -758,10 +843,12 @@ void asx_launch_fwd_cols(const AsxDev &P, const float *src, const float *smp, fl
 void asx_launch_rows(const AsxDev &P, const float2 *zxa, const float2 *zya, float2 *ga, int npairs,
                      hipStream_t s)
 {
-    dim3 grid(P.M1 / 2 + 1, npairs);
+    const int ntasks = (P.M1 / 2 + 1) * npairs;
+    const size_t lds = asx_lds_bytes_rows(P);
 #define ASX_LAUNCH(MAXR) \
-    do { allow_big_lds((const void *)k_rows<MAXR>, asx_lds_bytes_rows(P)); \
-         hipLaunchKernelGGL(k_rows<MAXR>, grid, dim3(P.threads_rows), asx_lds_bytes_rows(P), s, P.self_dev, zxa, zya, ga); } while (0)
+    do { allow_big_lds((const void *)k_rows<MAXR>, lds); \
+         int grid = ntasks; /* one task (pair, k1) per block */ \
+         hipLaunchKernelGGL(k_rows<MAXR>, dim3(grid), dim3(P.threads_rows), lds, s, P.self_dev, zxa, zya, ga, npairs); } while (0)
     const int mr = max_radix(P.st2);
     if (mr <= 10) ASX_LAUNCH(10); else if (mr <= 12) ASX_LAUNCH(12); else ASX_LAUNCH(16);
 #undef ASX_LAUNCH
