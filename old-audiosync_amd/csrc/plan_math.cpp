@@ -143,6 +143,16 @@ std::string asx_host_plan_build(size_t N, const char *split_override, AsxHostPla
     const int rows_max = (int)(ASX_LDS_ROWS_MAX / (4 * sizeof(float2)));
 
     int M1 = 0, M2 = 0, T = 0;
+    // Measured-best splits for the reference's six interval lengths (src/audiosync.c:50-57) on
+    // MI355X, from tools_tune.py (batched float32 path).  Other lengths use the cost model below.
+    static const struct { uint32_t M; const char *split; } kTuned[] = {
+        { 144000u, "120x1200x32" }, { 288000u, "600x480x16" }, { 480000u, "480x1000x16" },
+        { 720000u, "1200x600x8" },  { 960000u, "960x1000x8" }, { 1440000u, "1200x1200x8" },
+    };
+    if (!(split_override && *split_override)) {
+        for (const auto &t : kTuned)
+            if (t.M == M && F == 2 * (uint64_t)N) split_override = t.split;
+    }
     if (split_override && *split_override) {
         if (sscanf(split_override, "%dx%dx%d", &M1, &M2, &T) != 3 || M1 < 1 || M2 < 1 ||
             (uint64_t)M1 * (uint64_t)M2 != M || T < 2 || (T & (T - 1)) || T > 64 ||

@@ -51,6 +51,17 @@ __device__ __forceinline__ float2 tw_F(const AsxDev &P, uint32_t p)
 // {re0, re1, im0, im1} of two adjacent columns (lds_fft.h), so one thread transforms two
 // columns with shared twiddles, packed arithmetic and b128 LDS accesses.
 // ---------------------------------------------------------------------------
+// Tile <-> block mapping of the column kernels.  With T = 8 a tile row is a 64-byte segment,
+// half of a 128-byte L2 line; the neighbouring tile owns the other half.  Blocks are dealt
+// round-robin over the 8 XCDs (each with a private L2), so with the identity mapping the two
+// halves are fetched by two different L2s: the PMC read counters showed exactly 2x the needed
+// bytes.  This mapping puts tiles 2i and 2i+1 on blocks b and b+8 (same XCD, dispatched
+// together), so the second half hits in L2.  Speed only; any placement is correct.
+__device__ __forceinline__ int col_tile_of_block(int b)
+{
+    return (b & ~15) + 2 * (b & 7) + ((b >> 3) & 1);
+}
+
 __device__ __forceinline__ LdsLayout col_layout(const AsxDev &P)
 {
     LdsLayout L;
@@ -72,7 +83,8 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_fwd_cols(const AsxDe
                                                                       float2 *__restrict__ zya)
 {
     const AsxDev &P = *Pp; // plan constants live in device memory: uniform scalar loads
-    const int tile = blockIdx.x;
+    const int tile = col_tile_of_block(blockIdx.x);
+    if (tile >= P.ntiles) return; // grid.x is rounded up to a multiple of 16
     const bool is_smp = blockIdx.y != 0;
     const size_t pair = blockIdx.z;
     const int T = P.T, logH = P.logT - 1, H = T >> 1, M1 = P.M1, M2 = P.M2;
@@ -424,7 +436,8 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_inv_cols(const AsxDe
     __shared__ asx_peak_t tile_best;
     __shared__ uint32_t ncand;
     __shared__ AsxCand lcand[ASX_CAND_TILE];
-    const int tile = blockIdx.x;
+    const int tile = col_tile_of_block(blockIdx.x);
+    if (tile >= P.ntiles) return; // grid.x is rounded up to a multiple of 16
     const size_t pair = blockIdx.y;
     const int T = P.T, logH = P.logT - 1, H = T >> 1, M1 = P.M1, M2 = P.M2;
     const int c0 = tile * T;
@@ -831,7 +844,7 @@ static void allow_big_lds(const void *fn, size_t bytes)
 void asx_launch_fwd_cols(const AsxDev &P, const float *src, const float *smp, float2 *zxa,
                          float2 *zya, int npairs, hipStream_t s)
 {
-    dim3 grid(P.ntiles, 2, npairs);
+    dim3 grid((P.ntiles + 15) / 16 * 16, 2, npairs);
 #define ASX_LAUNCH(MAXR) \
     do { allow_big_lds((const void *)k_fwd_cols<MAXR>, asx_lds_bytes_cols(P)); \
          hipLaunchKernelGGL(k_fwd_cols<MAXR>, grid, dim3(P.threads_cols), asx_lds_bytes_cols(P), s, P.self_dev, src, smp, zxa, zya); } while (0)
@@ -857,7 +870,7 @@ void asx_launch_rows(const AsxDev &P, const float2 *zxa, const float2 *zya, floa
 void asx_launch_inv_cols(const AsxDev &P, const float2 *ga, const AsxPeakWs &W, float *r_out, int npairs,
                          hipStream_t s)
 {
-    dim3 grid(P.ntiles, npairs);
+    dim3 grid((P.ntiles + 15) / 16 * 16, npairs);
 #define ASX_LAUNCH(MAXR) \
     do { allow_big_lds((const void *)k_inv_cols<MAXR>, asx_lds_bytes_cols(P)); \
          hipLaunchKernelGGL(k_inv_cols<MAXR>, grid, dim3(P.threads_cols), asx_lds_bytes_cols(P), s, P.self_dev, ga, W, r_out); } while (0)
