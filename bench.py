@@ -26,8 +26,6 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 BYTES_PER_FRAME = 52             # A(N) = 52*N bytes per cross-correlation
-# share of A(N) attributed to each kernel family (DESIGN.md "Algorithmic bytes")
-KERNEL_ALGO_BYTES = {"fwd_cols": 28, "rows": 16 + 0, "inv_cols": 0, "pearson": 8}
 
 
 def cpu_baseline(sample_len, seconds_budget=20.0):
@@ -76,6 +74,7 @@ def main():
     import torch.distributed as dist
     import __graft_entry__ as graft
     asx = graft.load()
+    from audiosync_amd import sharding
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -106,11 +105,8 @@ def main():
         plan.xcorr_batch_dev(d_src.data_ptr(), d_smp.data_ptr(), batch, d_lag.data_ptr(),
                              d_coef.data_ptr(), d_ret.data_ptr(), stream)
         if world > 1:
-            # the only exchange on this path: gather (lag, coef, ret) of every shard
-            out_lag = [torch.empty_like(d_lag) for _ in range(world)]
-            out_coef = [torch.empty_like(d_coef) for _ in range(world)]
-            dist.all_gather(out_lag, d_lag)
-            dist.all_gather(out_coef, d_coef)
+            # the only exchange on this path: RCCL all-gather of (lag, coef, ret) of every shard
+            sharding.gather_results(d_lag, d_coef, d_ret, batch * world)
 
     for _ in range(args.warmup):
         step()
@@ -145,23 +141,40 @@ def main():
         pairs_total = batch * world * args.steps
         value = pairs_total / dt
         groups = (batch + plan.group - 1) // plan.group
-        dom = max(("fwd_cols", "rows", "inv_cols", "pearson"), key=lambda k: timings[k])
-        # roofline of the whole path over the in-stream time of one step (events), and of the
-        # dominant kernel on its own share of the algorithmic bytes
-        path_gbs = BYTES_PER_FRAME * n * batch / (timings["total"] * 1e-3) / 1e9
+        per_launch_pairs = min(batch, plan.group)
+        fam = ("fwd_cols", "rows", "inv_cols", "pearson")
+        dom = max(fam, key=lambda k: timings[k])
+        # DESIGN.md "Algorithmic bytes": A(N) = 52*N per cross-correlation, attributed
+        # to the kernel that moves them: fwd_cols 28N (inputs in, both spectra out), rows 16N (both
+        # spectra in), inv_cols 0 (its 8N read is an intermediate, not algorithmic), pearson 8N.
+        algo_share = {"fwd_cols": 28, "rows": 16, "inv_cols": 0, "pearson": 8}
         dom_launch_ms = timings[dom] / groups
-        dom_bytes = {"fwd_cols": 28, "rows": 24, "inv_cols": 8, "pearson": 8}[dom] * n * min(batch, plan.group)
+        dom_bytes = algo_share[dom] * n * per_launch_pairs
+        achieved = dom_bytes / (dom_launch_ms * 1e-3) / 1e9
+        path_gbs = BYTES_PER_FRAME * n * batch / (timings["total"] * 1e-3) / 1e9
+        m1, m2, tcols = plan.split
+        split = "%dx%dx%d" % (m1, m2, tcols)
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r1_traffic.json")
+        if os.path.exists(tpath):
+            # HBM bytes per launch from the PMC counters (tools_traffic.sh: separate --pmc passes,
+            # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes); only if it is this workload
+            tj = json.load(open(tpath))
+            c = tj.get("config", {})
+            if c.get("sample_len") == n and c.get("split") == split and c.get("group") == plan.group:
+                for kname, kv in tj["kernels"].items():
+                    if kname.startswith("k_" + dom):
+                        traffic = kv["hbm_bytes_per_launch"]
         roofline = {
-            "bound": "hbm", "achieved": path_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": path_gbs / HBM_PEAK_GBS, "traffic": None,
-            "basis": "52*N algorithmic bytes per pair over the event-timed stream time of one batch",
-            "dominant_kernel": {"name": "k_" + dom, "avg_launch_ms": dom_launch_ms,
-                                "launches_per_step": groups,
-                                "achieved_GBs": dom_bytes / (dom_launch_ms * 1e-3) / 1e9,
-                                "bytes_per_launch": dom_bytes},
+            "bound": "hbm", "kernel": "k_" + dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": dom_launch_ms,
+            "launches_per_step": groups, "pairs_per_launch": per_launch_pairs,
+            "path": {"algorithmic_bytes_per_pair": BYTES_PER_FRAME * n, "achieved": path_gbs,
+                     "frac": path_gbs / HBM_PEAK_GBS,
+                     "basis": "52*N bytes per pair over the event-timed in-stream time of one step"},
             "kernel_ms_per_step": {k: timings[k] for k in ("fwd_cols", "rows", "inv_cols", "finalize", "pearson", "total")},
         }
-        m1, m2, tcols = plan.split
         line = {
             "metric": "cross-correlations/sec (N=%d float32 pairs)" % n,
             "value": value, "unit": "cross-correlations/s", "n_gpus": world, "steps": args.steps,
@@ -170,7 +183,8 @@ def main():
             "config": {"workload": "batched xcorr, N=%d frames/sample (source 2N), %d pairs per GPU per step, "
                                    "48 kHz mono float32, planted delays, SNR 0 dB" % (n, batch),
                        "sample_len": n, "pairs_per_gpu": batch, "group": plan.group,
-                       "split": "%dx%dx%d" % (m1, m2, tcols), "threads_cols_rows": list(plan.threads), "parallelism": "pairs sharded over %d GPU(s), RCCL all_gather of results" % world},
+                       "split": split, "threads_cols_rows": list(plan.threads),
+                       "parallelism": "pairs sharded over %d GPU(s), RCCL all_gather of results" % world},
             "results_ok": ok,
             "roofline": roofline,
         }
