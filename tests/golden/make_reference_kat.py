@@ -78,4 +78,25 @@ pcase("pc4_nan", "tests/test_pearson_coefficient.c:50-56", [1, 2, 3, 4], [0, 0, 
 
 with open(os.path.join(HERE, "reference_kat.json"), "w") as f:
     json.dump({"cross_correlation": xc, "pearson_coefficient": pc}, f)
+
+# plain-text copy for tests/c/kat_runner.c (no JSON parser in C):
+#   X <name> <n> <ret> <lag> <mode> <bound>   then 2n source values, n sample values
+#   P <name> <n> <mode> <value>               then n + n values
+# mode: E coef == bound, G coef > bound, L coef < bound, N NaN / no check
+with open(os.path.join(HERE, "reference_kat.txt"), "w") as f:
+    for c in xc:
+        e = c["expect"]
+        mode, bound = "N", 0.0
+        if "coef_eq" in e: mode, bound = "E", e["coef_eq"]
+        if "coef_gt" in e: mode, bound = "G", e["coef_gt"]
+        if "coef_lt" in e: mode, bound = "L", e["coef_lt"]
+        f.write("X %s %d %d %d %s %r\n" % (c["name"], len(c["sample"]), e["ret"], e.get("lag", 0), mode, bound))
+        f.write(" ".join(repr(float(v)) for v in c["source"]) + "\n")
+        f.write(" ".join(repr(float(v)) for v in c["sample"]) + "\n")
+    for c in pc:
+        e = c["expect"]
+        mode, bound = ("N", 0.0) if e.get("nan") else ("E", e["eq"])
+        f.write("P %s %d %s %r\n" % (c["name"], len(c["source_seg"]), mode, bound))
+        f.write(" ".join(repr(float(v)) for v in c["source_seg"]) + "\n")
+        f.write(" ".join(repr(float(v)) for v in c["sample_seg"]) + "\n")
 print("wrote", len(xc), "+", len(pc), "cases")

@@ -1,0 +1,78 @@
+"""The CPython module `audiosync` of this build: same behaviour the reference's own binding test
+checks (tests/test_bindings.py:11-54 there: debug round trip, setup(), run() on a thread with
+pause -> 'paused', resume -> 'running', abort -> 'idle', a second run/abort), plus the two
+additions (cross_correlation, set_feed)."""
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+import pytest
+
+import oracle
+from util import graft
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def audiosync():
+    graft.build()
+    sys.path.insert(0, graft.PKG_DIR)
+    import torch  # noqa: F401  (one HIP runtime per process: torch's, loaded first)
+    import audiosync as mod
+    return mod
+
+
+def test_surface_matches_reference_module(audiosync):
+    for name in ("run", "pause", "resume", "abort", "status", "setup", "get_debug", "set_debug"):
+        assert callable(getattr(audiosync, name)), name
+
+
+def test_debug_round_trip_and_setup(audiosync):
+    assert not audiosync.get_debug()
+    audiosync.set_debug(True)
+    assert audiosync.get_debug()
+    audiosync.set_debug(False)
+    assert not audiosync.get_debug()
+    assert audiosync.setup("test") is False      # no PulseAudio in this build
+    assert audiosync.status() == "idle"
+
+
+def test_cross_correlation_from_python(audiosync):
+    n = 48000
+    src, smp, true_lag = oracle.synth_pair(77, 1, n, 1)
+    ret, lag, coef = audiosync.cross_correlation(src.astype(np.float64), smp.astype(np.float64))
+    o_ret, o_lag, o_coef = oracle.cross_correlation(src, smp)
+    assert (ret, lag) == (o_ret, o_lag) and lag == true_lag and abs(coef - o_coef) < 1e-5
+    with pytest.raises(ValueError):
+        audiosync.cross_correlation(np.zeros(10), np.zeros(4))
+    with pytest.raises(TypeError):
+        audiosync.cross_correlation(np.zeros(10, dtype=np.float32), np.zeros(5, dtype=np.float32))
+
+
+def test_run_pause_resume_abort_state_machine(audiosync):
+    # a slow feed (frames_per_ms) keeps the run alive long enough to poke the state machine
+    rng = np.random.default_rng(0)
+    source = rng.uniform(-1, 1, 2 * 30 * 48000)
+    sample = 0.5 * source[1000: 1000 + 30 * 48000] + 0.01 * rng.uniform(-1, 1, 30 * 48000)
+    audiosync.set_feed(source, sample, 200)      # 200 frames/ms: the first interval needs > 1 s
+    result = {}
+    th = threading.Thread(target=lambda: result.update(r=audiosync.run("")))
+    th.start()
+    time.sleep(0.2)
+    audiosync.pause()
+    assert audiosync.status() == "paused"
+    audiosync.resume()
+    assert audiosync.status() == "running"
+    audiosync.abort()
+    th.join(timeout=60)
+    assert not th.is_alive()
+    assert audiosync.status() == "idle"
+    assert result["r"][1] is False               # aborted: (lag, False)
+    # second run, to completion this time: the planted delay in milliseconds
+    audiosync.set_feed(source, sample, 0)
+    lag_ms, ok = audiosync.run("again")
+    assert ok is True and lag_ms == round(1000 * 1000.0 / 48000.0)
+    assert audiosync.status() == "idle"
