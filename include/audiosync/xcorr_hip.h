@@ -109,6 +109,31 @@ int asx_xcorr_debug_r_dev(asx_plan *plan, const float *d_source, const float *d_
 int asx_pearson_f64(const double *source_seg, const double *sample_seg, size_t n, int device,
                     double *coefficient);
 
+/* ---- growing-window (streaming) mode ------------------------------------ */
+
+/* The reference re-runs the whole correlation on growing prefixes of the two
+ * tracks (3, 6, 10, 15, 20, 30 s; src/audiosync.c:50-57,226-259) and rebuilds
+ * plans and buffers every time.  A stream keeps both tracks resident in HBM:
+ * only NEW frames are uploaded (as the producers' f64le doubles,
+ * src/capture/linux_capture.c:370, and converted to float32 on the device),
+ * and one plan per prefix length is built once and reused. */
+typedef struct asx_stream asx_stream;
+
+/* Capacity: sample track max_sample_len frames, source track 2*max_sample_len. */
+asx_stream *asx_stream_create(size_t max_sample_len, int device);
+void asx_stream_destroy(asx_stream *stream);
+/* Append frames to the tracks (either count may be 0). -1 if capacity would be exceeded. */
+int asx_stream_append_f64(asx_stream *stream, const double *source_frames, size_t n_source,
+                          const double *sample_frames, size_t n_sample);
+/* Frames appended so far. */
+int asx_stream_lengths(const asx_stream *stream, size_t *n_source, size_t *n_sample);
+/* Forget all frames (plans stay). */
+int asx_stream_reset(asx_stream *stream);
+/* cross_correlation() on the prefixes source[0,2*sample_len), sample[0,sample_len) that are
+ * already resident.  Same return convention as asx_xcorr_f64.  -1 (outputs untouched) if
+ * fewer frames than that have been appended. */
+int asx_stream_xcorr(asx_stream *stream, size_t sample_len, long *lag, double *coefficient);
+
 /* ---- synthetic inputs and timing -------------------------------------- */
 
 /* Fill device buffers with pairs [first_pair, first_pair+count) of the

@@ -440,6 +440,137 @@ extern "C" int asx_pearson_f64(const double *a, const double *b, size_t n, int d
 }
 
 // ---------------------------------------------------------------------------
+// growing-window streams (BASELINE config 5)
+// ---------------------------------------------------------------------------
+struct asx_stream {
+    int device = 0;
+    size_t cap = 0;                 // max sample frames (source capacity = 2*cap)
+    size_t n_src = 0, n_smp = 0;    // frames resident
+    double *src64 = nullptr, *smp64 = nullptr;
+    float *src32 = nullptr, *smp32 = nullptr;
+    int64_t *d_lag = nullptr;
+    double *d_coef = nullptr;
+    int32_t *d_ret = nullptr;
+    std::vector<asx_plan *> plans;  // one per prefix length seen
+    std::mutex lock;
+};
+
+extern "C" void asx_stream_destroy(asx_stream *st)
+{
+    if (!st) return;
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    (void)hipSetDevice(st->device);
+    for (asx_plan *p : st->plans) asx_plan_destroy(p);
+    (void)hipFree(st->src64); (void)hipFree(st->smp64); (void)hipFree(st->src32); (void)hipFree(st->smp32);
+    (void)hipFree(st->d_lag); (void)hipFree(st->d_coef); (void)hipFree(st->d_ret);
+    (void)hipSetDevice(prev);
+    delete st;
+}
+
+extern "C" asx_stream *asx_stream_create(size_t max_sample_len, int device)
+{
+    if (max_sample_len == 0) { fail("asx_stream_create: max_sample_len must be > 0"); return nullptr; }
+    if (asx_device_count() == 0) { fail("no usable HIP device; this library has no CPU fallback"); return nullptr; }
+    if (device < 0) HIP_TRY_NULL(hipGetDevice(&device));
+    DevGuard dg(device);
+    if (!dg.ok) { fail("cannot select device %d", device); return nullptr; }
+    asx_stream *st = new asx_stream();
+    st->device = device;
+    st->cap = max_sample_len;
+    const size_t n = max_sample_len;
+    if (hipMalloc((void **)&st->src64, 2 * n * sizeof(double)) != hipSuccess ||
+        hipMalloc((void **)&st->smp64, n * sizeof(double)) != hipSuccess ||
+        hipMalloc((void **)&st->src32, 2 * n * sizeof(float)) != hipSuccess ||
+        hipMalloc((void **)&st->smp32, n * sizeof(float)) != hipSuccess ||
+        hipMalloc((void **)&st->d_lag, sizeof(int64_t)) != hipSuccess ||
+        hipMalloc((void **)&st->d_coef, sizeof(double)) != hipSuccess ||
+        hipMalloc((void **)&st->d_ret, sizeof(int32_t)) != hipSuccess) {
+        fail("asx_stream_create: hipMalloc failed: %s", hipGetErrorString(hipGetLastError()));
+        asx_stream_destroy(st);
+        return nullptr;
+    }
+    return st;
+}
+
+extern "C" int asx_stream_lengths(const asx_stream *st, size_t *n_source, size_t *n_sample)
+{
+    if (!st) return -1;
+    if (n_source) *n_source = st->n_src;
+    if (n_sample) *n_sample = st->n_smp;
+    return 0;
+}
+
+extern "C" int asx_stream_reset(asx_stream *st)
+{
+    if (!st) return -1;
+    std::lock_guard<std::mutex> guard(st->lock);
+    st->n_src = st->n_smp = 0;
+    return 0;
+}
+
+extern "C" int asx_stream_append_f64(asx_stream *st, const double *source_frames, size_t n_source,
+                                     const double *sample_frames, size_t n_sample)
+{
+    if (!st || (n_source && !source_frames) || (n_sample && !sample_frames))
+        return fail("asx_stream_append_f64: null argument");
+    std::lock_guard<std::mutex> guard(st->lock);
+    if (st->n_src + n_source > 2 * st->cap || st->n_smp + n_sample > st->cap)
+        return fail("asx_stream_append_f64: capacity exceeded");
+    DevGuard dg(st->device);
+    if (!dg.ok) return fail("cannot select device %d", st->device);
+    // the default stream orders these against the plans' streams through the blocking copies
+    if (n_source) {
+        HIP_TRY(hipMemcpy(st->src64 + st->n_src, source_frames, n_source * sizeof(double), hipMemcpyHostToDevice));
+        asx_launch_cvt_f64_f32(st->src64 + st->n_src, st->src32 + st->n_src, n_source, nullptr);
+    }
+    if (n_sample) {
+        HIP_TRY(hipMemcpy(st->smp64 + st->n_smp, sample_frames, n_sample * sizeof(double), hipMemcpyHostToDevice));
+        asx_launch_cvt_f64_f32(st->smp64 + st->n_smp, st->smp32 + st->n_smp, n_sample, nullptr);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    st->n_src += n_source;
+    st->n_smp += n_sample;
+    return 0;
+}
+
+extern "C" int asx_stream_xcorr(asx_stream *st, size_t sample_len, long *lag, double *coefficient)
+{
+    if (!st || !lag || !coefficient || sample_len == 0) return fail("asx_stream_xcorr: bad argument");
+    std::lock_guard<std::mutex> guard(st->lock);
+    if (st->n_smp < sample_len || st->n_src < 2 * sample_len)
+        return fail("asx_stream_xcorr: only %zu/%zu frames resident, %zu/%zu needed", st->n_src, st->n_smp,
+                    2 * sample_len, sample_len);
+    asx_plan *p = nullptr;
+    for (asx_plan *q : st->plans)
+        if (q->host.N == sample_len) p = q;
+    if (!p) {
+        p = asx_plan_create(sample_len, 1, st->device);
+        if (!p) return -1;
+        st->plans.push_back(p);
+    }
+    std::lock_guard<std::mutex> pguard(p->lock);
+    DevGuard dg(st->device);
+    if (!dg.ok) return fail("cannot select device %d", st->device);
+    hipStream_t s = p->stream;
+    p->ev_groups = 0;
+    if (run_group<double>(p, st->src32, st->smp32, st->src64, st->smp64, 1, st->d_lag, st->d_coef, st->d_ret,
+                          nullptr, s, 0))
+        return -1;
+    int64_t h_lag = 0;
+    double h_coef = 0;
+    int32_t h_ret = -1;
+    HIP_TRY(hipMemcpyAsync(&h_lag, st->d_lag, sizeof(h_lag), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(&h_coef, st->d_coef, sizeof(h_coef), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(&h_ret, st->d_ret, sizeof(h_ret), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    *lag = (long)h_lag;
+    *coefficient = h_coef;
+    return h_ret;
+}
+
+// ---------------------------------------------------------------------------
 // synthetic inputs, timing, raw memory helpers
 // ---------------------------------------------------------------------------
 extern "C" int asx_synth_pairs_dev(uint64_t seed, uint64_t first_pair, size_t count, size_t sample_len,

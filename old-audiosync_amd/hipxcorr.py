@@ -20,7 +20,8 @@ ABI_SYMBOLS = [
     "asx_device_count", "asx_last_error", "asx_abi_version", "asx_plan_create", "asx_plan_create_ex", "asx_plan_destroy",
     "asx_plan_sample_len", "asx_plan_fft_len", "asx_plan_split", "asx_plan_threads", "asx_plan_group",
     "asx_plan_workspace_bytes", "asx_xcorr_f64", "asx_xcorr_batch_f32", "asx_xcorr_batch_f32_dev",
-    "asx_xcorr_debug_r_dev", "asx_pearson_f64", "asx_synth_pairs_dev", "asx_plan_set_profiling",
+    "asx_xcorr_debug_r_dev", "asx_pearson_f64", "asx_stream_create", "asx_stream_destroy",
+    "asx_stream_append_f64", "asx_stream_lengths", "asx_stream_reset", "asx_stream_xcorr", "asx_synth_pairs_dev", "asx_plan_set_profiling",
     "asx_plan_last_timings_ms", "asx_device_malloc", "asx_device_free", "asx_memcpy_h2d",
     "asx_memcpy_d2h", "asx_stream_sync",
 ]
@@ -81,6 +82,18 @@ def lib():
     L.asx_xcorr_debug_r_dev.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
     L.asx_pearson_f64.restype = ctypes.c_int
     L.asx_pearson_f64.argtypes = [c_f64p, c_f64p, ctypes.c_size_t, ctypes.c_int, c_f64p]
+    L.asx_stream_create.restype = vp
+    L.asx_stream_create.argtypes = [ctypes.c_size_t, ctypes.c_int]
+    L.asx_stream_destroy.restype = None
+    L.asx_stream_destroy.argtypes = [vp]
+    L.asx_stream_append_f64.restype = ctypes.c_int
+    L.asx_stream_append_f64.argtypes = [vp, c_f64p, ctypes.c_size_t, c_f64p, ctypes.c_size_t]
+    L.asx_stream_lengths.restype = ctypes.c_int
+    L.asx_stream_lengths.argtypes = [vp, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]
+    L.asx_stream_reset.restype = ctypes.c_int
+    L.asx_stream_reset.argtypes = [vp]
+    L.asx_stream_xcorr.restype = ctypes.c_int
+    L.asx_stream_xcorr.argtypes = [vp, ctypes.c_size_t, ctypes.POINTER(ctypes.c_long), c_f64p]
     L.asx_synth_pairs_dev.restype = ctypes.c_int
     L.asx_synth_pairs_dev.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_size_t, ctypes.c_size_t,
                                       ctypes.c_int, vp, vp, vp, vp]
@@ -178,6 +191,43 @@ def synth_pairs_dev(seed, first_pair, count, sample_len, noise_shift, d_src, d_s
                                    d_lag or None, stream or None)
     if rc != 0:
         raise AsxError(_err())
+
+
+class Stream:
+    """asx_stream: both tracks resident in HBM, new frames appended, one plan per prefix length."""
+
+    def __init__(self, max_sample_len, device=-1):
+        self._h = lib().asx_stream_create(int(max_sample_len), int(device))
+        if not self._h:
+            raise AsxError(_err())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().asx_stream_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def append(self, source_frames, sample_frames):
+        s = np.ascontiguousarray(source_frames, dtype=np.float64)
+        t = np.ascontiguousarray(sample_frames, dtype=np.float64)
+        rc = lib().asx_stream_append_f64(self._h, s.ctypes.data_as(c_f64p), s.size, t.ctypes.data_as(c_f64p), t.size)
+        if rc != 0:
+            raise AsxError(_err())
+
+    def lengths(self):
+        a, b = ctypes.c_size_t(), ctypes.c_size_t()
+        lib().asx_stream_lengths(self._h, a, b)
+        return a.value, b.value
+
+    def reset(self):
+        lib().asx_stream_reset(self._h)
+
+    def xcorr(self, sample_len):
+        lag = ctypes.c_long(0)
+        coef = ctypes.c_double(0.0)
+        ret = lib().asx_stream_xcorr(self._h, int(sample_len), ctypes.byref(lag), ctypes.byref(coef))
+        return ret, lag.value, coef.value
 
 
 class Plan:

@@ -8,9 +8,14 @@
  * with the same signalling protocol (src/ffmpeg_pipe.c:63-149): signal
  * interval_done when an interval boundary is crossed, honour PAUSED_ST /
  * ABORT_ST between steps, zero-fill a short track and signal once more.
- * The consumer side -- wait for both producers, cross_correlation() on the
- * prefixes, first interval with coefficient >= MIN_CONFIDENCE wins, lag
- * converted to milliseconds -- follows src/audiosync.c:226-259.
+ * The consumer side -- wait for both producers, correlate the prefixes, first
+ * interval with coefficient >= MIN_CONFIDENCE wins, lag converted to
+ * milliseconds -- follows src/audiosync.c:226-259.  Where the reference calls
+ * cross_correlation() (:246) and so re-plans, re-allocates and re-reads both whole
+ * prefixes every interval, this loop keeps the tracks resident on the GPU
+ * (asx_stream): each interval uploads only the frames that arrived since the
+ * last one and reuses the plan of its length.  Result and error behaviour per
+ * interval are those of cross_correlation().
  */
 #include <math.h>
 #include <pthread.h>
@@ -21,6 +26,7 @@
 
 #include <audiosync/audiosync.h>
 #include <audiosync/cross_correlation.h>
+#include <audiosync/xcorr_hip.h>
 
 volatile global_status_t global_status = IDLE_ST;
 volatile int global_debug = 0;
@@ -191,6 +197,7 @@ int audiosync_run(const char *yt_title, long *lag)
         .intervals = interv_source, .n_intervals = N_INTERVALS,
     };
     struct producer_args cap_pa, down_pa;
+    asx_stream *stream = NULL;
 
     if (sample == NULL || source == NULL) {
         perror("audiosync: track buffer malloc failed");
@@ -216,6 +223,13 @@ int audiosync_run(const char *yt_title, long *lag)
     }
     down_started = 1;
 
+    /* both tracks live on the GPU for the whole run; freed at finish */
+    stream = asx_stream_create(LEN_SAMPLE, -1);
+    if (stream == NULL) {
+        fprintf(stderr, "audiosync: no GPU stream: %s\n", asx_last_error());
+        goto finish;
+    }
+
     LOG("starting interval loop");
     for (size_t i = 0; i < N_INTERVALS; i++) {
         pthread_mutex_lock(&mutex);
@@ -230,8 +244,15 @@ int audiosync_run(const char *yt_title, long *lag)
 
         LOG("next interval (%ld): cap=%ld down=%ld", (long) i, (long) have_cap, (long) have_down);
 
-        if (cross_correlation(source, sample, interv_sample[i], lag, &confidence) < 0)
+        /* upload what is new since the previous interval, then correlate the prefixes */
+        size_t up_src = 0, up_smp = 0;
+        asx_stream_lengths(stream, &up_src, &up_smp);
+        if (asx_stream_append_f64(stream, source + up_src, interv_source[i] - up_src,
+                                  sample + up_smp, interv_sample[i] - up_smp) < 0)
             continue;
+        if (asx_stream_xcorr(stream, interv_sample[i], lag, &confidence) < 0)
+            continue;
+        LOG("%ld frames of delay with a confidence of %f", *lag, confidence);
         if (confidence >= MIN_CONFIDENCE) {
             *lag = round((double) (*lag) * FRAMES_TO_MS);
             ret = 0;
@@ -240,6 +261,7 @@ int audiosync_run(const char *yt_title, long *lag)
     }
 
 finish:
+    if (stream) asx_stream_destroy(stream);
     audiosync_abort();
     if (cap_started) pthread_join(cap_th, NULL);
     if (down_started) pthread_join(down_th, NULL);

@@ -287,3 +287,32 @@ def test_full_size_planted_delay_and_oracle(mod, torch):
     src = d_src[: 2 * n].cpu().numpy(); smp = d_smp[:n].cpu().numpy()
     o_ret, o_lag, o_coef = oracle.cross_correlation(src, smp)
     assert o_ret == 0 and o_lag == int(d_lag[0]) and abs(o_coef - float(d_coef[0])) < COEF_TOL
+
+
+# ---- growing-window (streaming) mode: BASELINE config 5 --------------------------------------
+
+def test_stream_growing_window_matches_oracle(mod):
+    """prefixes 3 s -> 6 s -> 10 s of one pair; only new frames are uploaded; plans are reused"""
+    sr = 48000
+    n_max = 10 * sr
+    src, smp, true_lag = oracle.synth_pair(31, 4, n_max, 1)
+    src = src.astype(np.float64)
+    smp = smp.astype(np.float64)
+    st = mod.Stream(n_max, 0)
+    up_s = up_t = 0
+    for seconds in (3, 6, 10, 6, 3):          # growing, then re-using the cached plans
+        n = seconds * sr
+        if 2 * n > up_s:
+            st.append(src[up_s: 2 * n], smp[up_t: n])
+            up_s, up_t = 2 * n, n
+        assert st.lengths() == (up_s, up_t)
+        ret, lag, coef = st.xcorr(n)
+        o_ret, o_lag, o_coef = oracle.cross_correlation(src[: 2 * n], smp[:n])
+        assert (ret, lag) == (o_ret, o_lag) and abs(coef - o_coef) < COEF_TOL, seconds
+    with pytest.raises(mod.AsxError):
+        st.append(np.zeros(1), np.zeros(1))      # beyond capacity
+    assert st.xcorr(n_max)[0] in (0, -1)
+    st.reset()
+    assert st.lengths() == (0, 0)
+    assert st.xcorr(3 * sr)[0] == -1             # nothing resident any more
+    st.close()
