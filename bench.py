@@ -58,6 +58,75 @@ def cpu_baseline(sample_len, seconds_budget=20.0):
                       "%d threads, single-pair latency %.3f s" % (done, sample_len, workers, one)}
 
 
+def side_mode(args):
+    """BASELINE configs 2 and 5 on one GPU; not the driver's contract line, same JSON style."""
+    import numpy as np
+    import torch
+    import __graft_entry__ as graft
+    import oracle
+    asx = graft.load()
+    torch.cuda.set_device(0)
+    sr = 48000
+    n_max = 30 * sr
+    src32, smp32, true_lag = oracle.synth_pair(20260101, 0, n_max, 1)
+    if args.mode == "streaming":
+        # a delay every prefix can see (the generator's is up to +-0.75*N of the 30 s window)
+        true_lag = 12345
+        rng = np.random.default_rng(1)
+        smp32 = (0.5 * src32[true_lag: true_lag + n_max] + 0.25 * rng.uniform(-1, 1, n_max)).astype(np.float32)
+    src, smp = src32.astype(np.float64), smp32.astype(np.float64)
+    out = {"n_gpus": 1, "data": "synthetic", "dtype": "f32", "true_lag": int(true_lag)}
+    if args.mode == "streaming":
+        seconds = (3, 6, 10, 15, 20, 30)                       # src/audiosync.c:50-57
+        st = asx.Stream(n_max, 0)
+        for s_ in seconds:                                      # plans built once, outside the timing
+            st.append(src[st.lengths()[0]: 2 * s_ * sr], smp[st.lengths()[1]: s_ * sr]); st.xcorr(s_ * sr)
+        per = {}
+        reps = max(1, args.steps)
+        t_all = 0.0
+        for _ in range(reps):
+            st.reset()
+            for s_ in seconds:
+                n = s_ * sr
+                t0 = time.perf_counter()
+                a, b = st.lengths()
+                st.append(src[a: 2 * n], smp[b: n])
+                ret, lag, coef = st.xcorr(n)
+                dt = time.perf_counter() - t0
+                per[s_] = per.get(s_, 0.0) + dt / reps
+                t_all += dt / reps
+                assert ret == 0 and lag == true_lag
+        out.update({"metric": "growing-window run, 6 intervals 144000..1440000 frames, incremental upload + plan reuse",
+                    "value": t_all * 1e3, "unit": "ms", "higher_is_better": False,
+                    "ms_per_interval": {str(k): v * 1e3 for k, v in per.items()},
+                    "config": {"workload": "streaming 3/6/10/15/20/30 s prefixes of one 30 s pair, f64 host buffers"}})
+    else:
+        n = args.sample_len
+        plan = asx.Plan(n, 1, 0, split=args.split)
+        d_src = torch.from_numpy(src32[: 2 * n]).cuda(); d_smp = torch.from_numpy(smp32[:n]).cuda()
+        d_lag = torch.zeros(1, dtype=torch.int64, device="cuda"); d_coef = torch.zeros(1, dtype=torch.float64, device="cuda")
+        d_ret = torch.zeros(1, dtype=torch.int32, device="cuda")
+        stream = torch.cuda.current_stream().cuda_stream
+        def resident():
+            plan.xcorr_batch_dev(d_src.data_ptr(), d_smp.data_ptr(), 1, d_lag.data_ptr(), d_coef.data_ptr(), d_ret.data_ptr(), stream)
+            torch.cuda.synchronize()
+        def dropin():
+            return plan.xcorr_f64(src[: 2 * n], smp[:n])
+        for f in (resident, dropin):
+            for _ in range(3): f()
+        reps = max(5, args.steps)
+        t0 = time.perf_counter()
+        for _ in range(reps): resident()
+        t_res = (time.perf_counter() - t0) / reps
+        t0 = time.perf_counter()
+        for _ in range(reps): dropin()
+        t_abi = (time.perf_counter() - t0) / reps
+        out.update({"metric": "single pair latency N=%d" % n, "value": t_res * 1e3, "unit": "ms", "higher_is_better": False,
+                    "resident_float32_ms": t_res * 1e3, "double_abi_incl_h2d_ms": t_abi * 1e3,
+                    "config": {"workload": "one pair, N=%d; resident float32 vs cross_correlation(double*) incl. PCIe" % n}})
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -68,7 +137,12 @@ def main():
     ap.add_argument("--noise-shift", type=int, default=1)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--split", default=None)
+    ap.add_argument("--mode", default="batched", choices=["batched", "streaming", "single"],
+                    help="batched = the headline workload (default); streaming = BASELINE config 5 "
+                         "(growing window 3..30 s, plan reuse); single = config 2 (one pair, latency)")
     args = ap.parse_args()
+    if args.mode != "batched":
+        return side_mode(args)
 
     import torch
     import torch.distributed as dist
