@@ -475,29 +475,51 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_inv_cols(const AsxDe
     __syncthreads();
     lds_fft<MAXR, true, true>(lds4, P.st1, Lc, P.tw1, pre);
 
-    // running maximum per thread: a thread meets its lags in increasing order, so the strict
-    // '>' keeps the earliest of equal keys, like the reference's sequential scan.
-    float best_key = -INFINITY;
-    uint32_t best_idx = 0xFFFFFFFFu;
-    for (int e = threadIdx.x; e < nelem4; e += blockDim.x) {
-        const int cg = e & (H - 1), j1 = e >> logH;
-        const int j2 = c0 + 2 * cg;
-        if (j2 < M2) {
-            const uint32_t i0 = 2u * ((uint32_t)j1 * (uint32_t)M2 + (uint32_t)j2);
+    // Peak search.  A thread meets its lags in increasing order, so a strict '>' keeps the
+    // earliest of equal keys, like the reference's sequential scan (src/cross_correlation.c:60).
+    // Fast path (block-uniform): the tile is full, every lag counts, lag 0 (the signed one) is
+    // not in it and r is not being dumped -> two packed max per slot, indices resolved at the end.
+    const bool fast = even && (c0 + T <= M2) && (P.nout == P.F) && (tile != 0) && (r_out == nullptr);
+    asx_peak_t best = 0;
+    if (fast) {
+        float best_m = -INFINITY;
+        int best_e = -1;
+        for (int e = threadIdx.x; e < nelem4; e += blockDim.x) {
             const float4 g = lds4[e];
-            const float val[4] = { g.x, g.z, g.y, g.w }; // slot = {re0, re1, im0, im1}
+            const float m = fmaxf(fmaxf(fabsf(g.x), fabsf(g.y)), fmaxf(fabsf(g.z), fabsf(g.w))); // NaNs drop out
+            if (m > best_m) { best_m = m; best_e = e; }
+        }
+        if (best_e >= 0) {
+            const int cg = best_e & (H - 1), j1 = best_e >> logH;
+            const uint32_t i0 = 2u * ((uint32_t)j1 * (uint32_t)M2 + (uint32_t)(c0 + 2 * cg));
+            const float4 g = lds4[best_e];
+            // lag order inside a slot {re0, re1, im0, im1}: re0, im0, re1, im1
+            const uint32_t h = fabsf(g.x) == best_m ? 0u : fabsf(g.z) == best_m ? 1u : fabsf(g.y) == best_m ? 2u : 3u;
+            best = peak_pack_key(best_m, i0 + h);
+        }
+    } else {
+        float best_key = -INFINITY;
+        uint32_t best_idx = 0xFFFFFFFFu;
+        for (int e = threadIdx.x; e < nelem4; e += blockDim.x) {
+            const int cg = e & (H - 1), j1 = e >> logH;
+            const int j2 = c0 + 2 * cg;
+            if (j2 < M2) {
+                const uint32_t i0 = 2u * ((uint32_t)j1 * (uint32_t)M2 + (uint32_t)j2);
+                const float4 g = lds4[e];
+                const float val[4] = { g.x, g.z, g.y, g.w }; // slot = {re0, re1, im0, im1}
 #pragma unroll
-            for (int h = 0; h < 4; h++) {
-                const uint32_t idx = i0 + h;
-                if (idx < P.nout && j2 + (h >> 1) < M2) {
-                    const float key = peak_key_of(val[h], idx);
-                    if (key > best_key) { best_key = key; best_idx = idx; }
-                    if (r_out) r_out[pair * (size_t)P.nout + idx] = val[h];
+                for (int h = 0; h < 4; h++) {
+                    const uint32_t idx = i0 + h;
+                    if (idx < P.nout && j2 + (h >> 1) < M2) {
+                        const float key = peak_key_of(val[h], idx);
+                        if (key > best_key) { best_key = key; best_idx = idx; }
+                        if (r_out) r_out[pair * (size_t)P.nout + idx] = val[h];
+                    }
                 }
             }
         }
+        best = best_idx == 0xFFFFFFFFu ? 0 : peak_pack_key(best_key, best_idx);
     }
-    asx_peak_t best = best_idx == 0xFFFFFFFFu ? 0 : peak_pack_key(best_key, best_idx);
     best = block_peak_max(best, red);
     if (threadIdx.x == 0) tile_best = best;
     __syncthreads();
@@ -506,11 +528,15 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_inv_cols(const AsxDe
     // float32 accuracy.  A lag near the GLOBAL maximum is necessarily near its tile's maximum.
     const float thr = near_max_threshold(peak_key(tile_best));
     for (int e = threadIdx.x; e < nelem4; e += blockDim.x) {
+        const float4 g = lds4[e];
+        if (fast) {
+            const float m = fmaxf(fmaxf(fabsf(g.x), fabsf(g.y)), fmaxf(fabsf(g.z), fabsf(g.w)));
+            if (!(m >= thr)) continue; // almost every slot
+        }
         const int cg = e & (H - 1), j1 = e >> logH;
         const int j2 = c0 + 2 * cg;
         if (j2 < M2) {
             const uint32_t i0 = 2u * ((uint32_t)j1 * (uint32_t)M2 + (uint32_t)j2);
-            const float4 g = lds4[e];
             const float val[4] = { g.x, g.z, g.y, g.w }; // slot = {re0, re1, im0, im1}
 #pragma unroll
             for (int h = 0; h < 4; h++) {
