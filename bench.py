@@ -225,7 +225,7 @@ def main():
         dom_launch_ms = timings[dom] / groups
         dom_bytes = algo_share[dom] * n * per_launch_pairs
         achieved = dom_bytes / (dom_launch_ms * 1e-3) / 1e9
-        path_gbs = BYTES_PER_FRAME * n * batch / (timings["total"] * 1e-3) / 1e9
+        path_gbs = BYTES_PER_FRAME * n * value / world / 1e9   # per GPU, from the timed steps
         m1, m2, tcols = plan.split
         split = "%dx%dx%d" % (m1, m2, tcols)
         traffic = None
@@ -246,7 +246,7 @@ def main():
             "launches_per_step": groups, "pairs_per_launch": per_launch_pairs,
             "path": {"algorithmic_bytes_per_pair": BYTES_PER_FRAME * n, "achieved": path_gbs,
                      "frac": path_gbs / HBM_PEAK_GBS,
-                     "basis": "52*N bytes per pair over the event-timed in-stream time of one step"},
+                     "basis": "52*N bytes per pair x pairs/s per GPU of the timed steps (two stream lanes overlapped); kernel_ms_per_step is one serialized, event-timed step"},
             "kernel_ms_per_step": {k: timings[k] for k in ("fwd_cols", "rows", "inv_cols", "finalize", "pearson", "total")},
         }
         line = {

@@ -72,11 +72,20 @@ struct asx_plan {
 
     // device tables
     std::vector<void *> allocs; // everything to hipFree on destroy
-    // workspaces for one group
-    float2 *zxa = nullptr, *zya = nullptr, *ga = nullptr;
-    AsxPeakWs pk{};
-    AsxSeg *seg = nullptr;
-    double *psums = nullptr;
+    // Two "lanes": each owns the workspaces of one launch group and a stream.  Consecutive
+    // groups of a batch alternate lanes, so the (memory-bound) column kernels of one group run
+    // beside the (issue/latency-bound) row kernel of the other instead of each leaving half the
+    // chip idle in turn.
+    struct Lane {
+        hipStream_t stream = nullptr;
+        hipEvent_t done = nullptr;
+        float2 *zxa = nullptr, *zya = nullptr, *ga = nullptr;
+        AsxPeakWs pk{};
+        AsxSeg *seg = nullptr;
+        double *psums = nullptr;
+    } lanes[2];
+    int nlanes = 2;
+    hipEvent_t fork = nullptr;
     // staging for the host-pointer entry points (lazy)
     float *st_src = nullptr, *st_smp = nullptr;
     int64_t *st_lag = nullptr;
@@ -135,22 +144,28 @@ static int plan_init(asx_plan *p, size_t N, size_t max_batch, const char *split)
 
     // group size: keep the three inter-kernel intermediates (24*M bytes per pair) of one
     // group around the size of the 256 MiB Infinity Cache so the next kernel re-reads them on die
-    size_t ws_mb = 1024;
+    size_t ws_mb = 2048;
     if (const char *e = getenv("ASX_WS_MB")) ws_mb = (size_t)atol(e) > 0 ? (size_t)atol(e) : ws_mb;
     size_t per_pair = (size_t)3 * h.M * sizeof(float2);
-    size_t g = (ws_mb << 20) / per_pair;
+    size_t g = (ws_mb << 20) / per_pair / 2; // two lanes share the budget
     if (g < 1) g = 1;
     if (g > 65535) g = 65535; // grid.y / grid.z limit
     if (max_batch < 1) max_batch = 1;
     if (g > max_batch) g = max_batch;
     p->group = g;
-    if (dev_alloc(p, &p->zxa, g * h.M) || dev_alloc(p, &p->zya, g * h.M) || dev_alloc(p, &p->ga, g * h.M) ||
-        dev_alloc(p, &p->pk.partials, g * (size_t)h.ntiles) || dev_alloc(p, &p->pk.cand_n, g * (size_t)h.ntiles) ||
-        dev_alloc(p, &p->pk.cand, g * (size_t)h.ntiles * ASX_CAND_TILE) || dev_alloc(p, &p->pk.refine_n, g) ||
-        dev_alloc(p, &p->pk.refine_idx, g * ASX_CAND_PAIR) || dev_alloc(p, &p->pk.refine_val, g * ASX_CAND_PAIR) ||
-        dev_alloc(p, &p->seg, g) ||
-        dev_alloc(p, &p->psums, g * ASX_PEARSON_BLOCKS * 5))
-        return -1;
+    if (const char *e = getenv("ASX_LANES")) p->nlanes = atoi(e) == 1 ? 1 : 2;
+    for (int l = 0; l < p->nlanes; l++) {
+        asx_plan::Lane &ln = p->lanes[l];
+        if (dev_alloc(p, &ln.zxa, g * h.M) || dev_alloc(p, &ln.zya, g * h.M) || dev_alloc(p, &ln.ga, g * h.M) ||
+            dev_alloc(p, &ln.pk.partials, g * (size_t)h.ntiles) || dev_alloc(p, &ln.pk.cand_n, g * (size_t)h.ntiles) ||
+            dev_alloc(p, &ln.pk.cand, g * (size_t)h.ntiles * ASX_CAND_TILE) || dev_alloc(p, &ln.pk.refine_n, g) ||
+            dev_alloc(p, &ln.pk.refine_idx, g * ASX_CAND_PAIR) || dev_alloc(p, &ln.pk.refine_val, g * ASX_CAND_PAIR) ||
+            dev_alloc(p, &ln.seg, g) || dev_alloc(p, &ln.psums, g * ASX_PEARSON_BLOCKS * 5))
+            return -1;
+        HIP_TRY(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&ln.done, hipEventDisableTiming));
+    }
+    HIP_TRY(hipEventCreateWithFlags(&p->fork, hipEventDisableTiming));
     d.stamps = nullptr;
     if (getenv("ASX_STAMPS")) {
         unsigned long long *st = nullptr;
@@ -208,6 +223,11 @@ extern "C" void asx_plan_destroy(asx_plan *p)
     (void)hipGetDevice(&prev);
     (void)hipSetDevice(p->device);
     if (p->stream) { (void)hipStreamSynchronize(p->stream); (void)hipStreamDestroy(p->stream); }
+    for (auto &ln : p->lanes) {
+        if (ln.stream) { (void)hipStreamSynchronize(ln.stream); (void)hipStreamDestroy(ln.stream); }
+        if (ln.done) (void)hipEventDestroy(ln.done);
+    }
+    if (p->fork) (void)hipEventDestroy(p->fork);
     for (hipEvent_t ev : p->ev) (void)hipEventDestroy(ev);
     for (void *a : p->allocs) (void)hipFree(a);
     (void)hipSetDevice(prev);
@@ -274,29 +294,30 @@ static int prof_mark(asx_plan *p, hipStream_t s, size_t slot)
 template <typename TIn>
 static int run_group(asx_plan *p, const float *d_src, const float *d_smp, const TIn *p_src,
                      const TIn *p_smp, size_t g, int64_t *d_lag, double *d_coef, int32_t *d_ret,
-                     float *d_r, hipStream_t s, size_t group_index)
+                     float *d_r, hipStream_t s, size_t group_index, int lane = 0)
 {
     const AsxDev &P = p->dev;
+    asx_plan::Lane &W = p->lanes[lane];
     const size_t e0 = group_index * 6;
     if (prof_mark(p, s, e0 + 0)) return -1;
-    asx_launch_fwd_cols(P, d_src, d_smp, p->zxa, p->zya, (int)g, s);
+    asx_launch_fwd_cols(P, d_src, d_smp, W.zxa, W.zya, (int)g, s);
     if (prof_mark(p, s, e0 + 1)) return -1;
-    asx_launch_rows(P, p->zxa, p->zya, p->ga, (int)g, s);
+    asx_launch_rows(P, W.zxa, W.zya, W.ga, (int)g, s);
     if (prof_mark(p, s, e0 + 2)) return -1;
-    asx_launch_inv_cols(P, p->ga, p->pk, d_r, (int)g, s);
+    asx_launch_inv_cols(P, W.ga, W.pk, d_r, (int)g, s);
     if (prof_mark(p, s, e0 + 3)) return -1;
-    asx_launch_finalize(P, p->pk, p->seg, (int)g, s);
+    asx_launch_finalize(P, W.pk, W.seg, (int)g, s);
     if (sizeof(TIn) == sizeof(float))
-        asx_launch_refine_f32(P, (const float *)p_src, (const float *)p_smp, p->pk, p->seg, (int)g, s);
+        asx_launch_refine_f32(P, (const float *)p_src, (const float *)p_smp, W.pk, W.seg, (int)g, s);
     else
-        asx_launch_refine_f64(P, (const double *)p_src, (const double *)p_smp, p->pk, p->seg, (int)g, s);
+        asx_launch_refine_f64(P, (const double *)p_src, (const double *)p_smp, W.pk, W.seg, (int)g, s);
     if (prof_mark(p, s, e0 + 4)) return -1;
     if (sizeof(TIn) == sizeof(float))
         asx_launch_pearson_f32((const float *)p_src, (const float *)p_smp, 2 * (size_t)P.N, P.N, P.N,
-                               p->seg, p->psums, d_lag, d_coef, d_ret, (int)g, s);
+                               W.seg, W.psums, d_lag, d_coef, d_ret, (int)g, s);
     else
         asx_launch_pearson_f64((const double *)p_src, (const double *)p_smp, 2 * (size_t)P.N, P.N, P.N,
-                               p->seg, p->psums, d_lag, d_coef, d_ret, (int)g, s);
+                               W.seg, W.psums, d_lag, d_coef, d_ret, (int)g, s);
     if (prof_mark(p, s, e0 + 5)) return -1;
     HIP_TRY(hipGetLastError());
     return 0;
@@ -313,13 +334,30 @@ extern "C" int asx_xcorr_batch_f32_dev(asx_plan *p, const float *d_source, const
     hipStream_t s = stream ? (hipStream_t)stream : p->stream;
     const size_t N = p->host.N;
     p->ev_groups = 0;
+    // chunking: groups of at most `group` pairs; with two lanes a batch is cut into at least two
+    // chunks (when it is big enough to fill the chip twice) that alternate between the lanes
+    const bool overlap = (p->nlanes == 2) && !p->profiling && batch >= 8;
+    size_t chunk = p->group;
+    if (overlap && batch < 2 * chunk) chunk = (batch + 1) / 2;
+    if (overlap) {
+        HIP_TRY(hipEventRecord(p->fork, s));
+        for (int l = 0; l < 2; l++) HIP_TRY(hipStreamWaitEvent(p->lanes[l].stream, p->fork, 0));
+    }
     size_t gi = 0;
-    for (size_t done = 0; done < batch; done += p->group, gi++) {
-        const size_t g = std::min(p->group, batch - done);
+    for (size_t done = 0; done < batch; done += chunk, gi++) {
+        const size_t g = std::min(chunk, batch - done);
+        const int lane = overlap ? (int)(gi & 1) : 0;
+        hipStream_t ls = overlap ? p->lanes[lane].stream : s;
         if (run_group<float>(p, d_source + done * 2 * N, d_sample + done * N, d_source + done * 2 * N,
                              d_sample + done * N, g, d_lag ? d_lag + done : nullptr, d_coef + done,
-                             d_ret ? d_ret + done : nullptr, nullptr, s, gi))
+                             d_ret ? d_ret + done : nullptr, nullptr, ls, gi, lane))
             return -1;
+    }
+    if (overlap) {
+        for (int l = 0; l < 2; l++) {
+            HIP_TRY(hipEventRecord(p->lanes[l].done, p->lanes[l].stream));
+            HIP_TRY(hipStreamWaitEvent(s, p->lanes[l].done, 0));
+        }
     }
     p->ev_groups = p->profiling ? gi : 0;
     return 0;
