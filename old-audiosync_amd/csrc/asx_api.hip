@@ -72,10 +72,10 @@ struct asx_plan {
 
     // device tables
     std::vector<void *> allocs; // everything to hipFree on destroy
-    // Two "lanes": each owns the workspaces of one launch group and a stream.  Consecutive
-    // groups of a batch alternate lanes, so the (memory-bound) column kernels of one group run
-    // beside the (issue/latency-bound) row kernel of the other instead of each leaving half the
-    // chip idle in turn.
+    // "Lanes": each owns the workspaces of one launch group and a stream.  With two lanes
+    // (ASX_LANES=2) consecutive groups of a batch alternate lanes so that kernels of different
+    // groups may overlap; measured gain 0..4 %, less than simply doubling the group, so one
+    // lane is the default.
     struct Lane {
         hipStream_t stream = nullptr;
         hipEvent_t done = nullptr;
@@ -84,7 +84,7 @@ struct asx_plan {
         AsxSeg *seg = nullptr;
         double *psums = nullptr;
     } lanes[2];
-    int nlanes = 2;
+    int nlanes = 1;   // ASX_LANES=2 enables the second lane (measured: +0..4 %)
     hipEvent_t fork = nullptr;
     // staging for the host-pointer entry points (lazy)
     float *st_src = nullptr, *st_smp = nullptr;
@@ -144,16 +144,16 @@ static int plan_init(asx_plan *p, size_t N, size_t max_batch, const char *split)
 
     // group size: keep the three inter-kernel intermediates (24*M bytes per pair) of one
     // group around the size of the 256 MiB Infinity Cache so the next kernel re-reads them on die
-    size_t ws_mb = 2048;
+    size_t ws_mb = 4096;
     if (const char *e = getenv("ASX_WS_MB")) ws_mb = (size_t)atol(e) > 0 ? (size_t)atol(e) : ws_mb;
     size_t per_pair = (size_t)3 * h.M * sizeof(float2);
-    size_t g = (ws_mb << 20) / per_pair / 2; // two lanes share the budget
+    size_t g = (ws_mb << 20) / per_pair / (getenv("ASX_LANES") && atoi(getenv("ASX_LANES")) == 2 ? 2 : 1);
     if (g < 1) g = 1;
     if (g > 65535) g = 65535; // grid.y / grid.z limit
     if (max_batch < 1) max_batch = 1;
     if (g > max_batch) g = max_batch;
     p->group = g;
-    if (const char *e = getenv("ASX_LANES")) p->nlanes = atoi(e) == 1 ? 1 : 2;
+    if (const char *e = getenv("ASX_LANES")) p->nlanes = atoi(e) == 2 ? 2 : 1;
     for (int l = 0; l < p->nlanes; l++) {
         asx_plan::Lane &ln = p->lanes[l];
         if (dev_alloc(p, &ln.zxa, g * h.M) || dev_alloc(p, &ln.zya, g * h.M) || dev_alloc(p, &ln.ga, g * h.M) ||
