@@ -139,7 +139,7 @@ static int plan_init(asx_plan *p, size_t N, size_t max_batch, const char *split)
     if (dev_upload(p, &d.tw1, h.tw1) || dev_upload(p, &d.tw2, h.tw2) || dev_upload(p, &d.tw_lo, h.tw_lo) ||
         dev_upload(p, &d.tw_hi, h.tw_hi) || dev_upload(p, &d.tw_b, h.tw_b) ||
         dev_upload(p, &d.k1_of_pos1, h.k1_of_pos1) || dev_upload(p, &d.pos1_of_k1, h.pos1_of_k1) ||
-        dev_upload(p, &d.pos2_of_k2, h.pos2_of_k2))
+        dev_upload(p, &d.pos2_of_k2, h.pos2_of_k2) || dev_upload(p, &d.row_tasks, h.row_tasks))
         return -1;
 
     // group size: keep the three inter-kernel intermediates (24*M bytes per pair) of one

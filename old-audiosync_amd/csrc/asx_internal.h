@@ -65,6 +65,7 @@ struct AsxDev {
     const int *k1_of_pos1; // row slot -> k1
     const int *pos1_of_k1; // k1 -> row slot
     const int *pos2_of_k2; // k2 -> slot inside a row after the forward row transform
+    const int4 *row_tasks; // [M1/2+1] {slot of row k1, slot of row M1-k1, k1, M1-k1}: one load starts a k_rows block
     const AsxDev *self_dev; // device copy of this struct (what the kernels read)
     unsigned long long *stamps; // diagnostic builds (-DASX_STAMPS) only: per-block phase clocks of k_rows
 };

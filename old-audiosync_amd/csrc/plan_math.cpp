@@ -212,5 +212,10 @@ std::string asx_host_plan_build(size_t N, const char *split_override, AsxHostPla
     hp->k1_of_pos1.assign(M1, 0);
     for (int k = 0; k < M1; k++) hp->k1_of_pos1[hp->pos1_of_k1[k]] = k;
     hp->pos2_of_k2 = asx_position_table(hp->st2);
+    hp->row_tasks.resize(M1 / 2 + 1);
+    for (int k1 = 0; k1 <= M1 / 2; k1++) {
+        const int m1 = (M1 - k1) % M1;
+        hp->row_tasks[k1] = make_int4(hp->pos1_of_k1[k1], hp->pos1_of_k1[m1], k1, m1);
+    }
     return "";
 }

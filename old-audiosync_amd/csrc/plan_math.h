@@ -16,6 +16,7 @@ struct AsxHostPlan {
     AsxStages st1{}, st2{};
     std::vector<float2> tw1, tw2, tw_lo, tw_hi, tw_b;
     std::vector<int> k1_of_pos1, pos1_of_k1, pos2_of_k2;
+    std::vector<int4> row_tasks;
 };
 
 // LDS budgets that bound the split (bytes per workgroup).

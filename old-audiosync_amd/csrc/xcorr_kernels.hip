@@ -18,6 +18,7 @@
 #include "lds_fft.h"
 
 #include <math.h>
+#include <stdlib.h>
 
 // Diagnostic phase clocks (never in a shipped build; -DASX_STAMPS): lane 0 of every k_rows block
 // records s_memtime at phase boundaries into a buffer nothing else reads.
@@ -190,12 +191,15 @@ template <int MAXR>
 __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, ASX_ROWS_MIN_WAVES) void k_rows(const AsxDev *__restrict__ Pp,
                                                                   const float2 *__restrict__ zxa,
                                                                   const float2 *__restrict__ zya,
-                                                                  float2 *__restrict__ ga, int npairs)
+                                                                  float2 *__restrict__ ga,
+                                                                  const int4 *__restrict__ row_tasks,
+                                                                  int M1, int M2, uint32_t M)
 {
-    const AsxDev &P = *Pp; // plan constants live in device memory: uniform scalar loads
-    const int M1 = P.M1, M2 = P.M2;
+    // The start of a block is a chain of dependent memory accesses (plan struct -> index table ->
+    // rows); M1/M2/M and the task table come as kernel arguments so that ONE 16-byte load
+    // (slots and row numbers) separates the block from its row loads.
+    const AsxDev &P = *Pp; // the rest of the plan constants: device memory, uniform scalar loads
     const int nrows = M1 / 2 + 1;
-    (void)npairs;                            // task = (pair, k1) = blockIdx.x
     float4 *A4 = reinterpret_cast<float4 *>(asx_lds), *B4 = A4 + M2;
     float *Cf = reinterpret_cast<float *>(asx_lds);
     __shared__ float2 tw_step[2][ASX_ROW_STEPS];
@@ -204,12 +208,10 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, ASX_ROWS_MIN_WAVES) void k_row
     const int task = blockIdx.x;
     {
         const int pair = task / nrows;
-        const int k1 = task - pair * nrows;
-        const int m1 = (M1 - k1) % M1;
+        const int4 rt = row_tasks[task - pair * nrows];
+        const int pa = rt.x, pb = rt.y, k1 = rt.z, m1 = rt.w;
         const bool self = (k1 == m1);
         ASX_STAMP(0);
-        const int pa = P.pos1_of_k1[k1], pb = P.pos1_of_k1[m1];
-
         LdsLayout Lf;
         Lf.ngroups = self ? 1 : 2; Lf.log_ngroups = 0;
         Lf.elem_stride = 1; Lf.group_stride = M2;
@@ -219,7 +221,7 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, ASX_ROWS_MIN_WAVES) void k_row
         // every row load of the thread is issued first; the twiddle lookups below overlap them
         RowRegs L;
         {
-            const float2 *gx = zxa + (size_t)pair * P.M, *gy = zya + (size_t)pair * P.M;
+            const float2 *gx = zxa + (size_t)pair * M, *gy = zya + (size_t)pair * M;
             static_for<0, ASX_ROW_STEPS>([&](auto I) __attribute__((always_inline)) {
                 const int j2 = threadIdx.x + decltype(I)::value * blockDim.x;
                 L.xa[I] = L.ya[I] = L.xb[I] = L.yb[I] = make_float2(0.f, 0.f);
@@ -329,7 +331,7 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, ASX_ROWS_MIN_WAVES) void k_row
         ASX_STAMP(4);
 
         // inverse four-step twiddle conj(w_M^(k1*j2)) / conj(w_M^(m1*j2)), one per member
-        float2 *go = ga + (size_t)pair * P.M;
+        float2 *go = ga + (size_t)pair * M;
         const float2 twa = tw_F(P, 2u * (uint32_t)k1 * tcol); // looked up again: cheaper than 4 live VGPRs
         const float2 twb = tw_F(P, 2u * (uint32_t)m1 * tcol);
         for (int j2 = threadIdx.x, i = 0; j2 < M2; j2 += blockDim.x, i++) {
@@ -887,7 +889,8 @@ void asx_launch_rows(const AsxDev &P, const float2 *zxa, const float2 *zya, floa
 #define ASX_LAUNCH(MAXR) \
     do { allow_big_lds((const void *)k_rows<MAXR>, lds); \
          int grid = ntasks; /* one task (pair, k1) per block */ \
-         hipLaunchKernelGGL(k_rows<MAXR>, dim3(grid), dim3(P.threads_rows), lds, s, P.self_dev, zxa, zya, ga, npairs); } while (0)
+         if (const char *e_ = getenv("ASX_DEBUG_MAXTASKS")) grid = atoi(e_) < grid ? atoi(e_) : grid; /* timing experiments only */ \
+         hipLaunchKernelGGL(k_rows<MAXR>, dim3(grid), dim3(P.threads_rows), lds, s, P.self_dev, zxa, zya, ga, P.row_tasks, P.M1, P.M2, P.M); } while (0)
     const int mr = max_radix(P.st2);
     if (mr <= 10) ASX_LAUNCH(10); else if (mr <= 12) ASX_LAUNCH(12); else ASX_LAUNCH(16);
 #undef ASX_LAUNCH
