@@ -12,8 +12,8 @@
 // compile time (one Cooley-Tukey step in registers, constant inner twiddles),
 // so a length of 800..2000 takes THREE passes over LDS (three barriers) instead
 // of five or six.  The path is VALU-issue bound on gfx950 (one wave64 VALU
-// instruction per 4 cycles per SIMD), so everything here is written to issue
-// packed (v_pk_*) arithmetic on two transforms at once without lane swizzles.
+// instruction per 4 cycles per SIMD): two transforms per thread share twiddles and
+// index arithmetic; the floating-point work itself is plain scalar VALU (see v2f).
 // Stage twiddles w^(j*u) come from ONE (or two) table reads per butterfly and
 // a short product tree (depth <= 3), not R-1 gathered reads.
 // Index algebra is modelled and tested in tests/model_fourstep.py.
@@ -90,15 +90,26 @@ template <int R, int M> struct Root {
 
 // ---------------------------------------------------------------------------
 // Pair-planar complex arithmetic.  Every thread transforms TWO sequences at once (two
-// adjacent tile columns; or the X and Y spectra of one row; or the two rows of G): the
-// real parts of the pair share one 64-bit register pair, the imaginary parts another:
+// adjacent tile columns; or the X and Y spectra of one row; or the two rows of G) with the
+// same twiddles:
 //     Cx2.re = (re of member 0, re of member 1),  Cx2.im = (im of member 0, im of member 1)
-// so every complex add is two v_pk_add_f32, every multiply by a (shared) twiddle is four
-// v_pk_mul/fma_f32, and multiplications by +-i or conjugations are register renames with
-// sign modifiers -- no lane swizzles (the interleaved re/im layout cost ~25% v_mov's).
-// In LDS an element pair is one float4 {re0, re1, im0, im1}: one ds_read_b128 fills a Cx2.
+// Stage twiddles are generated once per pair, multiplications by +-i or conjugations are
+// register renames with sign modifiers, and in LDS an element pair is one float4
+// {re0, re1, im0, im1}: one ds_read_b128 fills a Cx2.
 // ---------------------------------------------------------------------------
-typedef float v2f __attribute__((ext_vector_type(2)));
+// Two floats moved together, computed separately.  An ext_vector_type(2) here makes hipcc emit
+// v_pk_add/mul/fma_f32; measured on gfx950 those are an anti-lever (k_rows 2.29 ms packed vs
+// 1.86 ms scalar for the same algebra), so the arithmetic is scalar on purpose and the kernels
+// are built with -fno-slp-vectorize so that LLVM does not re-pack it.
+struct v2f {
+    float x, y;
+};
+__device__ __forceinline__ v2f operator+(v2f a, v2f b) { return v2f{ a.x + b.x, a.y + b.y }; }
+__device__ __forceinline__ v2f operator-(v2f a, v2f b) { return v2f{ a.x - b.x, a.y - b.y }; }
+__device__ __forceinline__ v2f operator-(v2f a) { return v2f{ -a.x, -a.y }; }
+__device__ __forceinline__ v2f operator*(v2f a, v2f b) { return v2f{ a.x * b.x, a.y * b.y }; }
+__device__ __forceinline__ v2f operator*(v2f a, float b) { return v2f{ a.x * b, a.y * b }; }
+__device__ __forceinline__ v2f operator*(float b, v2f a) { return v2f{ a.x * b, a.y * b }; }
 
 struct Cx2 {
     v2f re, im;

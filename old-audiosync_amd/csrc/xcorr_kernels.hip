@@ -33,7 +33,7 @@
 #endif
 
 #ifndef ASX_ROWS_MIN_WAVES
-#define ASX_ROWS_MIN_WAVES 3   // k_rows needs ~140 VGPRs with radix 12: three waves per SIMD without spills
+#define ASX_ROWS_MIN_WAVES 4   // k_rows fits 128 VGPRs (112 with radix 12, scalar arithmetic): four blocks per CU
 #endif
 
 extern __shared__ __attribute__((aligned(16))) float2 asx_lds[];
