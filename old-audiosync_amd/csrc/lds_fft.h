@@ -336,8 +336,10 @@ __device__ __forceinline__ void lds_stage(float4 *lds, const AsxStages &st, int 
         } else {
             g = div_exact(w, nbf, inv_nbf, bf);
         }
-        int j;
-        const int b = div_exact(bf, q, inv_q, j);
+        int j, b;
+        if (UNIT_TW) { b = bf; j = 0; }                 // q == 1
+        else if (nbf == q) { b = 0; j = bf; }           // first stage: one sub-block (wave-uniform test)
+        else b = div_exact(bf, q, inv_q, j);
         float4 *p = lds + g * L.group_stride + (b * ns + j) * L.elem_stride;
         Cx2 v[R];
         static_for<0, R>([&](auto T) __attribute__((always_inline)) { v[T] = lds_get(p + T * step); });

@@ -104,8 +104,22 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_fwd_cols(const AsxDe
     const TwPre pre = tw_prefetch<true>(P.st1, 0, Lc, P.tw1);
     // all of a thread's tile loads are issued before the first is consumed (ASX_COL_LOADS per
     // round): a rolled loop would pay the HBM latency once per iteration
+    // Fast path (block-uniform): full tile, 16-byte aligned rows, no periodic extension, and the
+    // zero padding starts on a row boundary -> a row is either all data or all zeros.
+    const uint32_t row_reals = 2u * (uint32_t)M2;                 // real samples per matrix row
+    const bool fast = vec_in && (c0 + T <= M2) && (valid <= period) && (valid % row_reals == 0u);
+    const int data_rows = fast ? (int)(valid / row_reals) : 0;     // rows below this are all data
     for (int e0 = threadIdx.x; e0 < nelem4; e0 += ASX_COL_LOADS * blockDim.x) {
         float4 v[ASX_COL_LOADS];
+        if (fast) {
+            static_for<0, ASX_COL_LOADS>([&](auto I) __attribute__((always_inline)) {
+                const int e = e0 + decltype(I)::value * blockDim.x;
+                const int cg = e & (H - 1), j1 = e >> logH;
+                v[I] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (j1 < data_rows) // also false for e >= nelem4 (j1 >= M1 >= data_rows)
+                    v[I] = *reinterpret_cast<const float4 *>(in + 2 * ((size_t)j1 * M2 + c0 + 2 * cg));
+            });
+        } else {
         static_for<0, ASX_COL_LOADS>([&](auto I) __attribute__((always_inline)) {
             const int e = e0 + decltype(I)::value * blockDim.x;
             const int cg = e & (H - 1), j1 = e >> logH;
@@ -126,6 +140,7 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_fwd_cols(const AsxDe
                 }
             }
         });
+        }
         static_for<0, ASX_COL_LOADS>([&](auto I) __attribute__((always_inline)) {
             const int e = e0 + decltype(I)::value * blockDim.x;
             if (e < nelem4) lds4[e] = make_float4(v[I].x, v[I].z, v[I].y, v[I].w); // pair-planar
@@ -136,10 +151,14 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_fwd_cols(const AsxDe
 
     // slot p1 holds frequency k1 = k1_of_pos1[p1] and stays in that slot in HBM; the
     // four-step twiddle w_M^(k1*j2) is applied by k_rows, where k1 is block-uniform.
+    const bool full = even && (c0 + T <= M2);
     for (int e = threadIdx.x; e < nelem4; e += blockDim.x) {
         const int cg = e & (H - 1), p1 = e >> logH;
         const int j2 = c0 + 2 * cg;
-        if (j2 < M2) {
+        if (full) {
+            const float4 v = lds4[e];
+            *reinterpret_cast<float4 *>(out + (size_t)p1 * M2 + j2) = make_float4(v.x, v.z, v.y, v.w);
+        } else if (j2 < M2) {
             const float4 v = lds4[e];
             float2 *o = out + (size_t)p1 * M2 + j2;
             if (even) {
@@ -457,7 +476,9 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_inv_cols(const AsxDe
             const int cg = e & (H - 1), p1 = e >> logH;
             const int j2 = c0 + 2 * cg;
             v[I] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (e < nelem4 && j2 < M2) {
+            if (even && (c0 + T <= M2)) { // block-uniform: full tile
+                if (e < nelem4) v[I] = *reinterpret_cast<const float4 *>(in + (size_t)p1 * M2 + j2);
+            } else if (e < nelem4 && j2 < M2) {
                 const float2 *g = in + (size_t)p1 * M2 + j2;
                 if (even) {
                     v[I] = *reinterpret_cast<const float4 *>(g);
