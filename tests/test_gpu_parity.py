@@ -316,3 +316,79 @@ def test_stream_growing_window_matches_oracle(mod):
     assert st.lengths() == (0, 0)
     assert st.xcorr(3 * sr)[0] == -1             # nothing resident any more
     st.close()
+
+
+# ---- more edge cases -------------------------------------------------------------------------
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 9, 3645])
+def test_tiny_and_odd_lengths(mod, n):
+    """N = 1..4 (degenerate transforms), odd N with a smooth 2N (3645 = 3^6*5: pairs of an odd-length
+    batch are not 16-byte aligned, so the vector load paths must not be taken blindly)"""
+    rng = np.random.default_rng(n)
+    batch = 5
+    src = rng.uniform(-1, 1, (batch, 2 * n)).astype(np.float32)
+    smp = rng.uniform(-1, 1, (batch, n)).astype(np.float32)
+    if n >= 9:
+        for b in range(batch):                       # plant a delay so the peak is unambiguous
+            d = (b * 7) % n
+            smp[b] = 0.5 * src[b, d: d + n] + 0.05 * smp[b]
+    with mod.Plan(n, batch, 0) as plan:
+        lag, coef, ret = plan.xcorr_batch_f32(src, smp)
+    for b in range(batch):
+        o_ret, o_lag, o_coef = oracle.cross_correlation(src[b], smp[b])
+        assert int(ret[b]) == o_ret and int(lag[b]) == o_lag, (n, b)
+        if o_ret == 0:
+            assert abs(float(coef[b]) - o_coef) < COEF_TOL
+
+
+def test_many_exact_ties_keep_smallest_index(mod):
+    """a periodic source gives dozens of exactly equal peaks: more candidates than the exact
+    re-evaluation takes -> the float32 argmax is kept; it must still be the earliest lag"""
+    n = 4096
+    period = 64
+    base = np.random.default_rng(5).integers(-4, 5, period).astype(np.float64)
+    src = np.tile(base, 2 * n // period)
+    smp = src[:n].copy()
+    with mod.Plan(n, 1, 0) as plan:
+        ret, lag, coef = plan.xcorr_f64(src, smp)
+    o_ret, o_lag, o_coef = oracle.cross_correlation(src, smp)
+    assert (ret, lag) == (o_ret, o_lag) == (0, 0) and coef == 1.0
+
+
+def test_nan_in_input_gives_minus_one(mod):
+    n = 1024
+    src, smp, _ = oracle.synth_pair(1, 1, n, 1)
+    smp = smp.copy()
+    smp[17] = np.nan
+    with mod.Plan(n, 1, 0) as plan:
+        lag, coef, ret = plan.xcorr_batch_f32(src, smp)
+    o_ret, o_lag, o_coef = oracle.cross_correlation(src, smp)
+    assert int(ret[0]) == o_ret == -1 and int(lag[0]) == o_lag and coef[0] != coef[0]
+
+
+def test_large_amplitudes(mod):
+    """the reference's own tests use values up to 700; int16-style full-scale audio is 3e4"""
+    n = 6000
+    src, smp, true_lag = oracle.synth_pair(4, 2, n, 2)
+    with mod.Plan(n, 1, 0) as plan:
+        lag, coef, ret = plan.xcorr_batch_f32(32767.0 * src, 32767.0 * smp)
+    assert int(lag[0]) == true_lag and int(ret[0]) == 0
+
+
+def test_concurrent_callers_through_the_reference_api(hostlib):
+    """cross_correlation() is re-entrant in the reference (SURVEY.md 8b "Threading")"""
+    import threading
+    n = 12000
+    cases = [oracle.synth_pair(9, p, n, 1) for p in range(8)]
+    expect = [oracle.cross_correlation(c[0], c[1]) for c in cases]
+    got = [None] * len(cases)
+
+    def work(i):
+        for _ in range(5):
+            got[i] = call_cross_correlation(hostlib, cases[i][0], cases[i][1])
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(cases))]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    for g, e in zip(got, expect):
+        assert g[0] == e[0] and g[1] == e[1] and abs(g[2] - e[2]) < COEF_TOL
