@@ -231,7 +231,7 @@ def main():
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "r1_traffic.json")
         if os.path.exists(tpath):
-            # HBM bytes per launch from the PMC counters (tools_traffic.sh: separate --pmc passes,
+            # HBM bytes per launch from the PMC counters (tools/traffic.sh: separate --pmc passes,
             # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes); only if it is this workload
             tj = json.load(open(tpath))
             c = tj.get("config", {})

@@ -389,22 +389,6 @@ __device__ __forceinline__ asx_peak_t peak_pack_key(float key, uint32_t idx)
     return ((asx_peak_t)b << 32) | (asx_peak_t)(0xFFFFFFFFu - idx);
 }
 
-__device__ __forceinline__ asx_peak_t peak_pack(float value, uint32_t idx)
-{
-    // key(0) = arr[0] SIGNED (:56), key(i) = fabs(arr[i]) (:59).  NaN never wins (:60),
-    // except that a NaN at index 0 is never beaten.
-    float key;
-    if (idx == 0u) {
-        key = (value != value) ? INFINITY : (value + 0.0f); // -0.0 -> +0.0 so it ties with |0|
-    } else {
-        key = fabsf(value);
-        if (key != key) key = -INFINITY;
-    }
-    uint32_t b = __float_as_uint(key);
-    b = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
-    return ((asx_peak_t)b << 32) | (asx_peak_t)(0xFFFFFFFFu - idx);
-}
-
 __device__ __forceinline__ asx_peak_t peak_max(asx_peak_t a, asx_peak_t b) { return a > b ? a : b; }
 
 __device__ __forceinline__ asx_peak_t wave_peak_max(asx_peak_t v)
@@ -910,7 +894,6 @@ void asx_launch_rows(const AsxDev &P, const float2 *zxa, const float2 *zya, floa
 #define ASX_LAUNCH(MAXR) \
     do { allow_big_lds((const void *)k_rows<MAXR>, lds); \
          int grid = ntasks; /* one task (pair, k1) per block */ \
-         if (const char *e_ = getenv("ASX_DEBUG_MAXTASKS")) grid = atoi(e_) < grid ? atoi(e_) : grid; /* timing experiments only */ \
          hipLaunchKernelGGL(k_rows<MAXR>, dim3(grid), dim3(P.threads_rows), lds, s, P.self_dev, zxa, zya, ga, P.row_tasks, P.M1, P.M2, P.M); } while (0)
     const int mr = max_radix(P.st2);
     if (mr <= 10) ASX_LAUNCH(10); else if (mr <= 12) ASX_LAUNCH(12); else ASX_LAUNCH(16);

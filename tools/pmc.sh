@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools_pmc.sh <outdir> <bench args...>   (run on the GPU box via gpurun)
+# usage: tools/pmc.sh <outdir> <bench args...>   (run on the GPU box via gpurun)
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/$1; shift
 mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY --output-format csv -d $OUT/sq1 -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu "$@" > $OUT/sq1.log 2>&1

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools_pmc_any.sh <outdir> "<counters>" [bench args]  -> per-kernel average of each counter
+# usage: tools/pmc_any.sh <outdir> "<counters>" [bench args]  -> per-kernel average of each counter
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/$1; CTRS=$2; shift; shift
 mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
 rocprofv3 --pmc $CTRS --output-format csv -d $OUT/p -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu "$@" > $OUT/p.log 2>&1

@@ -3,7 +3,7 @@
 import ctypes, os, sys
 import numpy as np
 os.environ["ASX_STAMPS"] = "1"
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import __graft_entry__ as g
 asx = g.load()

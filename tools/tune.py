@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """tuning aid (run on the GPU box): time every reasonable split of each production length."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import __graft_entry__ as g
 asx = g.load()
