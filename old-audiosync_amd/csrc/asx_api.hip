@@ -137,7 +137,7 @@ static int plan_init(asx_plan *p, size_t N, size_t max_batch, const char *split)
     if (const char *e = getenv("ASX_THREADS_COLS")) d.threads_cols = atoi(e);
     if (const char *e = getenv("ASX_THREADS_ROWS")) d.threads_rows = atoi(e);
     if (dev_upload(p, &d.tw1, h.tw1) || dev_upload(p, &d.tw2, h.tw2) || dev_upload(p, &d.tw_lo, h.tw_lo) ||
-        dev_upload(p, &d.tw_hi, h.tw_hi) || dev_upload(p, &d.tw_b, h.tw_b) ||
+        dev_upload(p, &d.tw_hi, h.tw_hi) ||
         dev_upload(p, &d.k1_of_pos1, h.k1_of_pos1) || dev_upload(p, &d.pos1_of_k1, h.pos1_of_k1) ||
         dev_upload(p, &d.pos2_of_k2, h.pos2_of_k2) || dev_upload(p, &d.row_tasks, h.row_tasks))
         return -1;
@@ -733,14 +733,14 @@ extern "C" int asx_planmath_table(size_t sample_len, const char *split, int whic
     return (int)t.size();
 }
 
-// twiddle tables: which = 0 tw1, 1 tw2, 2 tw_lo, 3 tw_hi, 4 tw_b ; out = interleaved re,im floats
+// twiddle tables: which = 0 tw1, 1 tw2, 2 tw_lo, 3 tw_hi ; out = interleaved re,im floats
 extern "C" int asx_planmath_twiddles(size_t sample_len, const char *split, int which, float *out, size_t cap)
 {
     AsxHostPlan h;
     std::string err = asx_host_plan_build(sample_len, split, &h);
     if (!err.empty()) return fail("%s", err.c_str());
     const std::vector<float2> &t =
-        which == 0 ? h.tw1 : which == 1 ? h.tw2 : which == 2 ? h.tw_lo : which == 3 ? h.tw_hi : h.tw_b;
+        which == 0 ? h.tw1 : which == 1 ? h.tw2 : which == 2 ? h.tw_lo : h.tw_hi;
     if (t.size() > cap) return fail("table larger than buffer");
     memcpy(out, t.data(), t.size() * sizeof(float2));
     return (int)t.size();

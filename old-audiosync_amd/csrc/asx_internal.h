@@ -61,7 +61,6 @@ struct AsxDev {
     const float2 *tw2;     // w_{M2}^q, q < M2
     const float2 *tw_lo;   // w_F^q, q < 2^ASX_TW_LOG
     const float2 *tw_hi;   // w_F^(h * 2^ASX_TW_LOG)
-    const float2 *tw_b;    // w_F^(M1*k2), k2 < M2
     const int *k1_of_pos1; // row slot -> k1
     const int *pos1_of_k1; // k1 -> row slot
     const int *pos2_of_k2; // k2 -> slot inside a row after the forward row transform

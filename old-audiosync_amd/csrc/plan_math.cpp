@@ -205,8 +205,6 @@ std::string asx_host_plan_build(size_t N, const char *split_override, AsxHostPla
     const uint32_t nhi = (uint32_t)((F + ASX_TW_LO - 1) >> ASX_TW_LOG) + 1;
     hp->tw_hi.resize(nhi);
     for (uint32_t h = 0; h < nhi; h++) hp->tw_hi[h] = unit_root((uint64_t)h << ASX_TW_LOG, F);
-    hp->tw_b.resize(M2);
-    for (int k2 = 0; k2 < M2; k2++) hp->tw_b[k2] = unit_root((uint64_t)M1 * k2, F);
 
     hp->pos1_of_k1 = asx_position_table(hp->st1);
     hp->k1_of_pos1.assign(M1, 0);

@@ -179,24 +179,24 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_fwd_cols(const AsxDe
 // the two rows of G, which the inverse transforms as one pair.  Self-paired rows
 // (k1 = 0, M1/2) use A only and carry zeros in the second member of C.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ void combine_pair(Cx2 Za, Cx2 Zb, float2 w, float2 &Gk, float2 &Gm)
+__device__ __forceinline__ void combine_pair(Cx2 Za, Cx2 Zb, float2 w2, float2 &Gk, float2 &Gm)
 {
-    // members of Za/Zb: (X, Y).  Real-FFT untangling of both spectra at once:
-    // E = (a + conj b)/2, O = -i (a - conj b)/2, X[k] = E + w O, X[M-k] = conj(E - w O)
-    const Cx2 E = Cx2{ 0.5f * (Za.re + Zb.re), 0.5f * (Za.im - Zb.im) };
-    const Cx2 O = Cx2{ 0.5f * (Za.im + Zb.im), -0.5f * (Za.re - Zb.re) };
-    const Cx2 wO = mulw(O, w);
-    const Cx2 K = E + wO;                 // (X[k], Y[k])
-    const Cx2 Mm = E - wO;                // conj of (X[M-k], Y[M-k])
-    const float2 Xk = make_float2(K.re.x, K.im.x), Yk = make_float2(K.re.y, K.im.y);
-    const float2 Xm = make_float2(Mm.re.x, -Mm.im.x), Ym = make_float2(Mm.re.y, -Mm.im.y);
-    // src/cross_correlation.c:232-233: arr1[i] *= conj(arr2[i])
-    const float2 Pk = cmulc(Xk, Yk), Pm = cmulc(Xm, Ym);
-    // inverse tangling: G[k] = (P[k] + conj P[M-k]) + i conj(w) (P[k] - conj P[M-k])
-    const float2 S = cadd(Pk, cconj(Pm)), D = csub(Pk, cconj(Pm));
-    const float2 V = cmulc(D, w);
-    Gk = make_float2(S.x - V.y, S.y + V.x);
-    Gm = make_float2(S.x + V.y, V.x - S.y);
+    // Za = (Zx[k], Zy[k]), Zb = (Zx[M-k], Zy[M-k]); w2 = w_M^k.  With E' = a + conj b and
+    // O' = -i (a - conj b) (twice the even/odd parts of the real-FFT untangling), X[k] = (E'x + w O'x)/2
+    // etc.  Expanding P = X conj(Y) (src/cross_correlation.c:232-233) for k and M-k and the inverse
+    // tangling G[k] = (P[k] + conj P[M-k]) + i conj(w)(P[k] - conj P[M-k]) collapses to
+    //     W = E'x conj(E'y) + O'x conj(O'y),   U = O'x conj(E'y) + conj(w^2) E'x conj(O'y)
+    //     G[k] = (W + i U)/2,   G[M-k] = (conj W + i conj U)/2
+    // (checked against the step-by-step form in tests/model_fourstep.py): 40 real operations
+    // per pair of bins instead of 60, and X, Y, P never exist.
+    const Cx2 E = Cx2{ Za.re + Zb.re, Za.im - Zb.im };
+    const Cx2 O = Cx2{ Za.im + Zb.im, Zb.re - Za.re };
+    const float2 Ex = make_float2(E.re.x, E.im.x), Ey = make_float2(E.re.y, E.im.y);
+    const float2 Ox = make_float2(O.re.x, O.im.x), Oy = make_float2(O.re.y, O.im.y);
+    const float2 W = cadd(cmulc(Ex, Ey), cmulc(Ox, Oy));
+    const float2 U = cadd(cmulc(Ox, Ey), cmulc(cmulc(Ex, Oy), w2));
+    Gk = make_float2(0.5f * (W.x - U.y), 0.5f * (W.y + U.x));
+    Gm = make_float2(0.5f * (W.x + U.y), 0.5f * (U.x - W.y));
 }
 
 // Row loads of one task, all issued before the first is consumed.  (Issuing them one task
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, ASX_ROWS_MIN_WAVES) void k_row
         // ---- spectral combine.  Every thread first computes its G values into registers (it
         // reads slots other threads will overwrite), then, after a barrier, scatters them:
         // G[k] -> C[sa] member 0, G[M-k] -> C[sb] member 1 (member 0 for self-paired rows).
-        const float2 wA = tw_F(P, (uint32_t)k1); // w_F^k1, block-uniform
+        const float2 wA = tw_F(P, 2u * (uint32_t)k1); // w_M^k1, block-uniform; w_M^(k1 + M1*k2) = wA * w_M2^k2
         float2 gk[ASX_ROW_STEPS], gm[ASX_ROW_STEPS];
         int sa[ASX_ROW_STEPS], sb[ASX_ROW_STEPS]; // -1: nothing to write
         static_for<0, ASX_ROW_STEPS>([&](auto I) __attribute__((always_inline)) {
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, ASX_ROWS_MIN_WAVES) void k_row
             if (!self) {
                 if (k2 < M2) {
                     sa[i] = P.pos2_of_k2[k2]; sb[i] = P.pos2_of_k2[M2 - 1 - k2];
-                    combine_pair(lds_get(A4 + sa[i]), lds_get(B4 + sb[i]), cmul(wA, P.tw_b[k2]), gk[i], gm[i]);
+                    combine_pair(lds_get(A4 + sa[i]), lds_get(B4 + sb[i]), cmul(wA, P.tw2[k2]), gk[i], gm[i]);
                 }
             } else if (k1 == 0) {
                 if (k2 == 0) {
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, ASX_ROWS_MIN_WAVES) void k_row
                     const int m2 = M2 - k2;
                     sa[i] = P.pos2_of_k2[k2];
                     const int s2 = P.pos2_of_k2[m2];
-                    combine_pair(lds_get(A4 + sa[i]), lds_get(A4 + s2), P.tw_b[k2], gk[i], gm[i]);
+                    combine_pair(lds_get(A4 + sa[i]), lds_get(A4 + s2), P.tw2[k2], gk[i], gm[i]);
                     if (m2 != k2) sb[i] = s2;
                 }
             } else { // k1 == M1/2, M1 even
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, ASX_ROWS_MIN_WAVES) void k_row
                     const int m2 = M2 - 1 - k2;
                     sa[i] = P.pos2_of_k2[k2];
                     const int s2 = P.pos2_of_k2[m2];
-                    combine_pair(lds_get(A4 + sa[i]), lds_get(A4 + s2), cmul(wA, P.tw_b[k2]), gk[i], gm[i]);
+                    combine_pair(lds_get(A4 + sa[i]), lds_get(A4 + s2), cmul(wA, P.tw2[k2]), gk[i], gm[i]);
                     if (m2 != k2) sb[i] = s2;
                 }
             }

@@ -84,6 +84,16 @@ def combine(Zx, Zy, M1, M2):
     return G
 
 
+def combine_pair_collapsed(ax, bx, ay, by, k, M):
+    """the algebraically collapsed form k_rows uses (csrc/xcorr_kernels.hip::combine_pair):
+    returns G[k], G[M-k] from Zx[k], Zx[M-k], Zy[k], Zy[M-k]"""
+    Ex = ax + np.conj(bx); Ox = -1j * (ax - np.conj(bx))
+    Ey = ay + np.conj(by); Oy = -1j * (ay - np.conj(by))
+    W = Ex * np.conj(Ey) + Ox * np.conj(Oy)
+    U = Ox * np.conj(Ey) + np.conj(tw(M, k)) * Ex * np.conj(Oy)
+    return 0.5 * (W + 1j * U), 0.5 * (np.conj(W) + 1j * np.conj(U))
+
+
 def inv_rows(G, M1, M2):
     """end of kernel 2: inverse DFT over k2 of each row k1, then twiddle conj(w_M^(k1*j2)).
     in: G[k1][k2]  out: B[k1][j2]"""

@@ -143,3 +143,24 @@ def test_device_model_embedding_for_non_smooth_lengths(n):
     r = model.device_xcorr(src, smp) * (2 * n / F)
     ref = model.reference_r(src, smp)
     assert np.abs(r - ref).max() / np.abs(ref).max() < 1e-12
+
+
+def test_collapsed_combine_equals_step_by_step():
+    """k_rows computes G[k], G[M-k] with a collapsed formula; it must equal untangle -> X conj(Y) -> tangle"""
+    rng = np.random.default_rng(11)
+    M = 360
+    F = 2 * M
+    for k in (1, 2, 7, 90, 179, 180):
+        ax, bx, ay, by = (complex(*rng.normal(size=2)) for _ in range(4))
+        if k == M - k:
+            bx, by = ax, ay
+        w = model.tw(F, k)
+        Ex = 0.5 * (ax + np.conj(bx)); Ox = -0.5j * (ax - np.conj(bx))
+        Ey = 0.5 * (ay + np.conj(by)); Oy = -0.5j * (ay - np.conj(by))
+        Xk = Ex + w * Ox; Xm = np.conj(Ex - w * Ox)
+        Yk = Ey + w * Oy; Ym = np.conj(Ey - w * Oy)
+        Pk = Xk * np.conj(Yk); Pm = Xm * np.conj(Ym)
+        Gk = (Pk + np.conj(Pm)) + 1j * np.conj(w) * (Pk - np.conj(Pm))
+        Gm = (Pm + np.conj(Pk)) - 1j * w * (Pm - np.conj(Pk))
+        Ck, Cm = model.combine_pair_collapsed(ax, bx, ay, by, k, M)
+        assert abs(Ck - Gk) < 1e-12 and abs(Cm - Gm) < 1e-12
