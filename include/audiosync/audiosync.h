@@ -102,6 +102,13 @@ extern int audiosync_set_feed(const double *source, size_t source_len,
                               const double *sample, size_t sample_len,
                               unsigned frames_per_ms);
 
+/* Debug aid replacing the reference's compile-time PLOT/gnuplot dumps
+ * (src/cross_correlation.c:168-184,280-296): writes the two segments that
+ * pearson_coefficient() compares for `lag` (src/cross_correlation.c:256-271) as
+ * CSV lines "index,source,sample".  Returns the number of lines, -1 on error. */
+extern long audiosync_dump_segments_csv(const char *path, const double *source,
+                                        const double *sample, size_t sample_len, long lag);
+
 #ifdef __cplusplus
 }
 #endif

@@ -109,6 +109,17 @@ int asx_xcorr_debug_r_dev(asx_plan *plan, const float *d_source, const float *d_
 int asx_pearson_f64(const double *source_seg, const double *sample_seg, size_t n, int device,
                     double *coefficient);
 
+/* ---- result consumers ---------------------------------------------------- */
+
+/* What audiosync_run does with a result (src/audiosync.c:254-256,
+ * include/audiosync/audiosync.h:21,24), for a whole batch on the device:
+ *   accept[i]  = ret[i] == 0 && coef[i] >= min_confidence      (1 / 0)
+ *   lag_ms[i]  = round(lag[i] * 1000 / sample_rate)            (C round(): halves away from zero)
+ * All pointers are device pointers; d_accept may be NULL. Asynchronous on `stream`. */
+int asx_results_to_ms_dev(const int64_t *d_lag, const double *d_coef, const int32_t *d_ret,
+                          size_t batch, double min_confidence, double sample_rate,
+                          int64_t *d_lag_ms, int32_t *d_accept, void *stream);
+
 /* ---- growing-window (streaming) mode ------------------------------------ */
 
 /* The reference re-runs the whole correlation on growing prefixes of the two

@@ -478,6 +478,21 @@ extern "C" int asx_pearson_f64(const double *a, const double *b, size_t n, int d
 }
 
 // ---------------------------------------------------------------------------
+// result consumers
+// ---------------------------------------------------------------------------
+extern "C" int asx_results_to_ms_dev(const int64_t *d_lag, const double *d_coef, const int32_t *d_ret, size_t batch,
+                                     double min_confidence, double sample_rate, int64_t *d_lag_ms,
+                                     int32_t *d_accept, void *stream)
+{
+    if (!d_lag || !d_coef || !d_ret || !d_lag_ms) return fail("asx_results_to_ms_dev: null argument");
+    if (!(sample_rate > 0.0)) return fail("asx_results_to_ms_dev: bad sample rate");
+    asx_launch_results_to_ms(d_lag, d_coef, d_ret, batch, min_confidence, sample_rate, d_lag_ms, d_accept,
+                             (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
 // growing-window streams (BASELINE config 5)
 // ---------------------------------------------------------------------------
 struct asx_stream {

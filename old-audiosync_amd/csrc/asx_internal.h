@@ -115,6 +115,9 @@ void asx_launch_pearson_f32(const float *src, const float *smp, size_t src_pitch
 void asx_launch_pearson_f64(const double *src, const double *smp, size_t src_pitch, size_t smp_pitch,
                             uint32_t basis_len, const AsxSeg *seg, double *psums, int64_t *lag,
                             double *coef, int32_t *ret, int npairs, hipStream_t s);
+void asx_launch_results_to_ms(const int64_t *lag, const double *coef, const int32_t *ret, size_t batch,
+                              double min_confidence, double sample_rate, int64_t *lag_ms, int32_t *accept,
+                              hipStream_t s);
 void asx_launch_cvt_f64_f32(const double *in, float *out, size_t n, hipStream_t s);
 void asx_launch_synth(uint64_t seed, uint64_t first_pair, size_t count, uint32_t N,
                       int noise_shift, float *src, float *smp, int64_t *true_lag, hipStream_t s);

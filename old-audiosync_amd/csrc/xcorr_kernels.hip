@@ -761,6 +761,23 @@ __global__ __launch_bounds__(64) void k_pearson_final(const AsxSeg *__restrict__
 }
 
 // ---------------------------------------------------------------------------
+// result consumers: the acceptance threshold and frames -> milliseconds of
+// src/audiosync.c:254-256 for a whole batch
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(ASX_THREADS) void k_results_to_ms(const int64_t *__restrict__ lag,
+                                                                const double *__restrict__ coef,
+                                                                const int32_t *__restrict__ ret, size_t batch,
+                                                                double min_confidence, double ms_per_frame,
+                                                                int64_t *__restrict__ lag_ms,
+                                                                int32_t *__restrict__ accept)
+{
+    const size_t i = (size_t)blockIdx.x * ASX_THREADS + threadIdx.x;
+    if (i >= batch) return;
+    lag_ms[i] = (int64_t)round((double)lag[i] * ms_per_frame);
+    if (accept) accept[i] = (ret[i] == 0 && coef[i] >= min_confidence) ? 1 : 0;
+}
+
+// ---------------------------------------------------------------------------
 // double -> float conversion of the reference's f64 buffers
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(ASX_THREADS) void k_cvt_f64_f32(const double *__restrict__ in,
@@ -947,6 +964,16 @@ void asx_launch_pearson_f64(const double *src, const double *smp, size_t src_pit
     hipLaunchKernelGGL(k_pearson_partial<double>, dim3(ASX_PEARSON_BLOCKS, npairs), dim3(ASX_THREADS), 0, s,
                        src, smp, src_pitch, smp_pitch, basis_len, seg, psums);
     hipLaunchKernelGGL(k_pearson_final, dim3(npairs), dim3(64), 0, s, seg, psums, lag, coef, ret);
+}
+
+void asx_launch_results_to_ms(const int64_t *lag, const double *coef, const int32_t *ret, size_t batch,
+                              double min_confidence, double sample_rate, int64_t *lag_ms, int32_t *accept,
+                              hipStream_t s)
+{
+    if (batch == 0) return;
+    const unsigned blocks = (unsigned)((batch + ASX_THREADS - 1) / ASX_THREADS);
+    hipLaunchKernelGGL(k_results_to_ms, dim3(blocks), dim3(ASX_THREADS), 0, s, lag, coef, ret, batch, min_confidence,
+                       1000.0 / sample_rate, lag_ms, accept);
 }
 
 void asx_launch_cvt_f64_f32(const double *in, float *out, size_t n, hipStream_t s)

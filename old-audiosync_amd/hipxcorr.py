@@ -20,7 +20,7 @@ ABI_SYMBOLS = [
     "asx_device_count", "asx_last_error", "asx_abi_version", "asx_plan_create", "asx_plan_create_ex", "asx_plan_destroy",
     "asx_plan_sample_len", "asx_plan_fft_len", "asx_plan_split", "asx_plan_threads", "asx_plan_group",
     "asx_plan_workspace_bytes", "asx_xcorr_f64", "asx_xcorr_batch_f32", "asx_xcorr_batch_f32_dev",
-    "asx_xcorr_debug_r_dev", "asx_pearson_f64", "asx_stream_create", "asx_stream_destroy",
+    "asx_xcorr_debug_r_dev", "asx_pearson_f64", "asx_results_to_ms_dev", "asx_stream_create", "asx_stream_destroy",
     "asx_stream_append_f64", "asx_stream_lengths", "asx_stream_reset", "asx_stream_xcorr", "asx_synth_pairs_dev", "asx_plan_set_profiling",
     "asx_plan_last_timings_ms", "asx_device_malloc", "asx_device_free", "asx_memcpy_h2d",
     "asx_memcpy_d2h", "asx_stream_sync",
@@ -82,6 +82,8 @@ def lib():
     L.asx_xcorr_debug_r_dev.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
     L.asx_pearson_f64.restype = ctypes.c_int
     L.asx_pearson_f64.argtypes = [c_f64p, c_f64p, ctypes.c_size_t, ctypes.c_int, c_f64p]
+    L.asx_results_to_ms_dev.restype = ctypes.c_int
+    L.asx_results_to_ms_dev.argtypes = [vp, vp, vp, ctypes.c_size_t, ctypes.c_double, ctypes.c_double, vp, vp, vp]
     L.asx_stream_create.restype = vp
     L.asx_stream_create.argtypes = [ctypes.c_size_t, ctypes.c_int]
     L.asx_stream_destroy.restype = None
@@ -184,6 +186,13 @@ def pearson_f64(source_seg, sample_seg, device=-1):
     if rc != 0:
         raise AsxError(_err())
     return out.value
+
+
+def results_to_ms_dev(d_lag, d_coef, d_ret, batch, d_lag_ms, d_accept=0, min_confidence=0.95, sample_rate=48000.0, stream=0):
+    rc = lib().asx_results_to_ms_dev(d_lag, d_coef, d_ret, batch, min_confidence, sample_rate, d_lag_ms,
+                                     d_accept or None, stream or None)
+    if rc != 0:
+        raise AsxError(_err())
 
 
 def synth_pairs_dev(seed, first_pair, count, sample_len, noise_shift, d_src, d_smp, d_lag=0, stream=0):

@@ -111,3 +111,24 @@ double pearson_coefficient(double *source_start, const double *source_end, doubl
     }
     return value;
 }
+
+/* CSV instead of gnuplot: the segments the coefficient is computed on (see audiosync.h). */
+long audiosync_dump_segments_csv(const char *path, const double *source, const double *sample,
+                                 size_t sample_len, long lag)
+{
+    if (!path || !source || !sample || sample_len == 0) return -1;
+    if (lag >= (long) sample_len || lag < -(long) sample_len) return -1;
+    /* src/cross_correlation.c:256-271 */
+    const double *s0 = lag < 0 ? source : source + lag;
+    const double *t0 = lag < 0 ? sample - lag : sample;
+    const size_t n = lag < 0 ? (size_t) ((long) sample_len + lag) : sample_len;
+    FILE *f = fopen(path, "w");
+    if (f == NULL) {
+        perror("audiosync: dump fopen failed");
+        return -1;
+    }
+    fprintf(f, "index,source,sample\n");
+    for (size_t i = 0; i < n; i++) fprintf(f, "%zu,%.17g,%.17g\n", i, s0[i], t0[i]);
+    fclose(f);
+    return (long) n;
+}

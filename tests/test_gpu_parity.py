@@ -392,3 +392,36 @@ def test_concurrent_callers_through_the_reference_api(hostlib):
     [t.join() for t in threads]
     for g, e in zip(got, expect):
         assert g[0] == e[0] and g[1] == e[1] and abs(g[2] - e[2]) < COEF_TOL
+
+
+# ---- result consumers --------------------------------------------------------
+
+def test_results_to_ms_epilogue(mod, torch):
+    lag = torch.tensor([0, 24, -24, 12345, -12345, 71, 72, 100], dtype=torch.int64, device="cuda")
+    coef = torch.tensor([1.0, 0.95, 0.949999, 0.99, 0.99, 0.5, 0.96, float("nan")], dtype=torch.float64, device="cuda")
+    ret = torch.tensor([0, 0, 0, 0, -1, 0, 0, -1], dtype=torch.int32, device="cuda")
+    ms = torch.zeros(8, dtype=torch.int64, device="cuda")
+    acc = torch.zeros(8, dtype=torch.int32, device="cuda")
+    mod.results_to_ms_dev(lag.data_ptr(), coef.data_ptr(), ret.data_ptr(), 8, ms.data_ptr(), acc.data_ptr())
+    torch.cuda.synchronize()
+    import math
+    want = [int(math.copysign(math.floor(abs(l) * 1000.0 / 48000.0 + 0.5), l)) for l in lag.tolist()]  # C round()
+    assert ms.tolist() == want       # e.g. 24 frames = 0.5 ms -> 1, -24 -> -1 (round half away from zero)
+    assert acc.tolist() == [1, 1, 0, 1, 0, 0, 1, 0]
+
+
+def test_segment_dump_csv(hostlib, tmp_path):
+    dp = ctypes.POINTER(ctypes.c_double)
+    hostlib.audiosync_dump_segments_csv.restype = ctypes.c_long
+    hostlib.audiosync_dump_segments_csv.argtypes = [ctypes.c_char_p, dp, dp, ctypes.c_size_t, ctypes.c_long]
+    n = 6
+    src = np.arange(12, dtype=np.float64)
+    smp = np.arange(100, 106, dtype=np.float64)
+    for lag, rows in ((2, 6), (-2, 4)):
+        path = str(tmp_path / ("seg%d.csv" % lag))
+        got = hostlib.audiosync_dump_segments_csv(path.encode(), src.ctypes.data_as(dp), smp.ctypes.data_as(dp), n, lag)
+        assert got == rows
+        lines = open(path).read().strip().splitlines()
+        assert lines[0] == "index,source,sample" and len(lines) == rows + 1
+        first = lines[1].split(",")
+        assert float(first[1]) == (2.0 if lag > 0 else 0.0) and float(first[2]) == (100.0 if lag > 0 else 102.0)
