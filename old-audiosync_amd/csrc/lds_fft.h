@@ -8,8 +8,9 @@
 // un-permuted: the spectral product only needs X and Y in the SAME order, and
 // index tables (pos2_of_k2) locate the k <-> M-k partners.
 //
-// Radices 2,3,4,5 are hand-written; 6,8,9,10,12,15,16 are built from them at
-// compile time (one Cooley-Tukey step in registers, constant inner twiddles),
+// Radices 2,3,4,5 are hand-written; 6,10,12,15 are built from them at compile time
+// by the prime-factor maps (no inner twiddles), 8,9,16 by one Cooley-Tukey step in
+// registers with constant inner twiddles,
 // so a length of 800..2000 takes THREE passes over LDS (three barriers) instead
 // of five or six.  The path is VALU-issue bound on gfx950 (one wave64 VALU
 // instruction per 4 cycles per SIMD): two transforms per thread share twiddles and
@@ -249,12 +250,47 @@ template <int R1, int R2, bool INV> struct BflyC {
     }
 };
 
-template <bool INV> struct Bfly<6, INV> : BflyC<2, 3, INV> {};
+// Coprime composite radix R = R1*R2 in registers by the prime-factor (Good-Thomas) maps:
+//   input  t = (R2*t1 + R1*t2) mod R,   output u with u = u1 (mod R1), u = u2 (mod R2)
+//   DFT_R[u] = sum_{t1,t2} x[t] w_R1^(t1*u1) w_R2^(t2*u2)
+// -- no inner twiddles at all, and both maps are compile-time register renames.  Radix 10 costs
+// 92 real operations per butterfly instead of 108, radix 12 104 instead of 120.
+template <int R1, int R2, bool INV> struct BflyP {
+    static constexpr int R = R1 * R2;
+    static constexpr int crt(int u1, int u2)
+    {
+        for (int u = 0; u < R; u++)
+            if (u % R1 == u1 && u % R2 == u2) return u;
+        return 0;
+    }
+    static __device__ __forceinline__ void run(Cx2 (&v)[R])
+    {
+        Cx2 a[R]; // a[R2*u1 + t2]
+        static_for<0, R2>([&](auto T2) __attribute__((always_inline)) {
+            constexpr int t2 = decltype(T2)::value;
+            Cx2 x[R1];
+            static_for<0, R1>([&](auto T1) __attribute__((always_inline)) {
+                x[T1] = v[(R2 * decltype(T1)::value + R1 * t2) % R];
+            });
+            Bfly<R1, INV>::run(x);
+            static_for<0, R1>([&](auto U1) __attribute__((always_inline)) { a[R2 * decltype(U1)::value + t2] = x[U1]; });
+        });
+        static_for<0, R1>([&](auto U1) __attribute__((always_inline)) {
+            constexpr int u1 = decltype(U1)::value;
+            Cx2 x[R2];
+            static_for<0, R2>([&](auto T2) __attribute__((always_inline)) { x[T2] = a[R2 * u1 + decltype(T2)::value]; });
+            Bfly<R2, INV>::run(x);
+            static_for<0, R2>([&](auto U2) __attribute__((always_inline)) { v[crt(u1, decltype(U2)::value)] = x[U2]; });
+        });
+    }
+};
+
+template <bool INV> struct Bfly<6, INV> : BflyP<2, 3, INV> {};
 template <bool INV> struct Bfly<8, INV> : BflyC<2, 4, INV> {};
 template <bool INV> struct Bfly<9, INV> : BflyC<3, 3, INV> {};
-template <bool INV> struct Bfly<10, INV> : BflyC<2, 5, INV> {};
-template <bool INV> struct Bfly<12, INV> : BflyC<3, 4, INV> {};
-template <bool INV> struct Bfly<15, INV> : BflyC<3, 5, INV> {};
+template <bool INV> struct Bfly<10, INV> : BflyP<2, 5, INV> {};
+template <bool INV> struct Bfly<12, INV> : BflyP<3, 4, INV> {};
+template <bool INV> struct Bfly<15, INV> : BflyP<3, 5, INV> {};
 template <bool INV> struct Bfly<16, INV> : BflyC<4, 4, INV> {};
 
 // ---------------------------------------------------------------------------
