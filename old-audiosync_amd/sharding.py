@@ -31,13 +31,15 @@ def gather_results(lag, coef, ret, total, group=None):
     base, extra = divmod(int(total), world)
     width = base + (1 if extra else 0)            # every rank sends `width` entries (padded)
 
-    def one(t, fill):
-        padded = torch.full((width,), fill, dtype=t.dtype, device=t.device)
-        padded[: t.numel()] = t
-        parts = [torch.empty_like(padded) for _ in range(world)]
-        dist.all_gather(parts, padded, group=group)
-        return torch.cat([parts[r][: shard_range(total, r, world)[1]] for r in range(world)])
-
     start, count = shard_range(total, rank, world)
     assert lag.numel() == count and coef.numel() == count and ret.numel() == count
-    return one(lag, 0), one(coef, float("nan")), one(ret, -1)
+    # ONE collective per batch: the three results travel as three float64 columns (a lag is an
+    # integer far below 2^53, ret is 0/-1: both exact in float64)
+    packed = torch.full((width, 3), float("nan"), dtype=torch.float64, device=coef.device)
+    packed[:count, 0] = lag.to(torch.float64)
+    packed[:count, 1] = coef
+    packed[:count, 2] = ret.to(torch.float64)
+    parts = [torch.empty_like(packed) for _ in range(world)]
+    dist.all_gather(parts, packed, group=group)
+    full = torch.cat([parts[r][: shard_range(total, r, world)[1]] for r in range(world)])
+    return full[:, 0].to(torch.int64), full[:, 1].contiguous(), full[:, 2].to(torch.int32)
