@@ -425,3 +425,32 @@ def test_segment_dump_csv(hostlib, tmp_path):
         assert lines[0] == "index,source,sample" and len(lines) == rows + 1
         first = lines[1].split(",")
         assert float(first[1]) == (2.0 if lag > 0 else 0.0) and float(first[2]) == (100.0 if lag > 0 else 102.0)
+
+
+# ---- BASELINE.json configurations at full size: planted delays (size-independent property) ----
+
+@pytest.mark.parametrize("n,batch,shift", [(288000, 1024, 1), (480000, 1024, 0), (144000, 512, -1)])
+def test_baseline_batches_recover_every_planted_delay(mod, torch, n, batch, shift):
+    d_src = torch.empty(batch * 2 * n, dtype=torch.float32, device="cuda")
+    d_smp = torch.empty(batch * n, dtype=torch.float32, device="cuda")
+    d_true = torch.empty(batch, dtype=torch.int64, device="cuda")
+    d_lag = torch.empty(batch, dtype=torch.int64, device="cuda")
+    d_coef = torch.empty(batch, dtype=torch.float64, device="cuda")
+    d_ret = torch.empty(batch, dtype=torch.int32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    mod.synth_pairs_dev(31337, 0, batch, n, shift, d_src.data_ptr(), d_smp.data_ptr(), d_true.data_ptr(), stream)
+    with mod.Plan(n, batch, 0) as plan:
+        plan.xcorr_batch_dev(d_src.data_ptr(), d_smp.data_ptr(), batch, d_lag.data_ptr(), d_coef.data_ptr(),
+                             d_ret.data_ptr(), stream)
+        torch.cuda.synchronize()
+    assert torch.equal(d_lag, d_true)
+    assert int(d_ret.abs().sum()) == 0
+    # Pearson of 0.5*s + noise against s: sqrt(SNR/(1+SNR)) with SNR = 4^shift / 4  (oracle/xcorr_oracle.h)
+    snr = (1.0 / 12.0) / ((1.0 / 3.0) * 4.0 ** (-shift))
+    want = (snr / (1.0 + snr)) ** 0.5
+    assert float((d_coef - want).abs().max()) < 0.02
+    # spot-check three pairs against the oracle itself
+    for i in (0, batch // 2, batch - 1):
+        src = d_src[i * 2 * n: (i + 1) * 2 * n].cpu().numpy(); smp = d_smp[i * n: (i + 1) * n].cpu().numpy()
+        o_ret, o_lag, o_coef = oracle.cross_correlation(src, smp)
+        assert o_ret == 0 and o_lag == int(d_lag[i]) and abs(o_coef - float(d_coef[i])) < COEF_TOL
