@@ -26,8 +26,8 @@
 // reference's rule is applied to the exact values, so near-ties that float32 transforms
 // cannot resolve (e.g. the reference's own sin(i) test, margin 3e-8) come out as in float64.
 #define ASX_REFINE_EPS 1.0e-4f
-#define ASX_CAND_TILE 8                     // candidates kept per column tile
-#define ASX_CAND_PAIR 32                    // candidates re-evaluated per pair (more -> float32 result kept)
+#define ASX_CAND_TILE 16                    // candidates kept per column tile
+#define ASX_CAND_PAIR 64                    // candidates re-evaluated per pair (more -> float32 result kept)
 
 // Radix schedule of one in-LDS transform of length n.
 // DIF stage i works on sub-blocks of length ns[i] = n / (radix[0]*...*radix[i-1]).
