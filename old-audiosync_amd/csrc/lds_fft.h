@@ -96,7 +96,7 @@ template <int R, int M> struct Root {
 //     Cx2.re = (re of member 0, re of member 1),  Cx2.im = (im of member 0, im of member 1)
 // Stage twiddles are generated once per pair, multiplications by +-i or conjugations are
 // register renames with sign modifiers, and in LDS an element pair is one float4
-// {re0, re1, im0, im1}: one ds_read_b128 fills a Cx2.
+// {re0, im0, re1, im1}: one ds_read_b128 fills a Cx2.
 // ---------------------------------------------------------------------------
 // Two floats moved together, computed separately.  An ext_vector_type(2) here makes hipcc emit
 // v_pk_add/mul/fma_f32; measured on gfx950 those are an anti-lever (k_rows 2.29 ms packed vs
@@ -135,12 +135,14 @@ __device__ __forceinline__ Cx2 mulwc(Cx2 a, float2 w)
 __device__ __forceinline__ Cx2 mul2(Cx2 a, Cx2 w) { return Cx2{ a.re * w.re - a.im * w.im, a.re * w.im + a.im * w.re }; }
 __device__ __forceinline__ Cx2 mul2c(Cx2 a, Cx2 w) { return Cx2{ a.re * w.re + a.im * w.im, a.im * w.re - a.re * w.im }; }
 
+// LDS slot = the two members' complex values side by side, {re0, im0, re1, im1}: for two adjacent
+// tile columns that is exactly how they lie in HBM, so tiles move in and out without a shuffle.
 __device__ __forceinline__ Cx2 lds_get(const float4 *p)
 {
     const float4 x = *p;
-    return Cx2{ v2f{ x.x, x.y }, v2f{ x.z, x.w } };
+    return Cx2{ v2f{ x.x, x.z }, v2f{ x.y, x.w } };
 }
-__device__ __forceinline__ void lds_put(float4 *p, Cx2 v) { *p = make_float4(v.re.x, v.re.y, v.im.x, v.im.y); }
+__device__ __forceinline__ void lds_put(float4 *p, Cx2 v) { *p = make_float4(v.re.x, v.im.x, v.re.y, v.im.y); }
 
 // a * w_R^M (forward) or a * conj(w_R^M) (INV), compile-time root
 template <int R, int M, bool INV> __device__ __forceinline__ Cx2 mul_root(Cx2 a)

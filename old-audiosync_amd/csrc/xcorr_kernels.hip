@@ -48,9 +48,9 @@ __device__ __forceinline__ float2 tw_F(const AsxDev &P, uint32_t p)
 
 // ---------------------------------------------------------------------------
 // Column tiles.  A tile is T columns (T even, a power of two) of the [M1][M2] matrix,
-// held in LDS as [M1][T/2] float4 slots; a slot is the pair-planar image
-// {re0, re1, im0, im1} of two adjacent columns (lds_fft.h), so one thread transforms two
-// columns with shared twiddles, packed arithmetic and b128 LDS accesses.
+// held in LDS as [M1][T/2] float4 slots; a slot is two adjacent columns as they lie in HBM,
+// {re0, im0, re1, im1} (lds_fft.h), so one thread transforms two columns with shared
+// twiddles and b128 LDS accesses, and tiles move in and out without a shuffle.
 // ---------------------------------------------------------------------------
 // Tile <-> block mapping of the column kernels.  With T = 8 a tile row is a 64-byte segment,
 // half of a 128-byte L2 line; the neighbouring tile owns the other half.  Blocks are dealt
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_fwd_cols(const AsxDe
         }
         static_for<0, ASX_COL_LOADS>([&](auto I) __attribute__((always_inline)) {
             const int e = e0 + decltype(I)::value * blockDim.x;
-            if (e < nelem4) lds4[e] = make_float4(v[I].x, v[I].z, v[I].y, v[I].w); // pair-planar
+            if (e < nelem4) lds4[e] = v[I];
         });
     }
     __syncthreads();
@@ -157,15 +157,15 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_fwd_cols(const AsxDe
         const int j2 = c0 + 2 * cg;
         if (full) {
             const float4 v = lds4[e];
-            *reinterpret_cast<float4 *>(out + (size_t)p1 * M2 + j2) = make_float4(v.x, v.z, v.y, v.w);
+            *reinterpret_cast<float4 *>(out + (size_t)p1 * M2 + j2) = v;
         } else if (j2 < M2) {
             const float4 v = lds4[e];
             float2 *o = out + (size_t)p1 * M2 + j2;
             if (even) {
-                *reinterpret_cast<float4 *>(o) = make_float4(v.x, v.z, v.y, v.w);
+                *reinterpret_cast<float4 *>(o) = v;
             } else {
-                o[0] = make_float2(v.x, v.z);
-                if (j2 + 1 < M2) o[1] = make_float2(v.y, v.w);
+                o[0] = make_float2(v.x, v.y);
+                if (j2 + 1 < M2) o[1] = make_float2(v.z, v.w);
             }
         }
     }
@@ -174,8 +174,8 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_fwd_cols(const AsxDe
 // ---------------------------------------------------------------------------
 // k_rows: grid (M1/2 + 1, npairs).  Block k1 handles spectrum rows k1 and m1 = M1 - k1
 // (the rows that hold each other's k <-> M-k partners).  LDS: A[M2], B[M2] float4 slots,
-// pair-planar over the two SPECTRA: A[e] = {Re X, Re Y, Im X, Im Y} of row k1, B of row m1.
-// After the spectral combine the same storage holds C[e] = {Re Ga, Re Gb, Im Ga, Im Gb},
+// pairing the two SPECTRA: A[e] = {X[e], Y[e]} of row k1, B of row m1.
+// After the spectral combine the same storage holds C[e] = {Ga[e], Gb[e]},
 // the two rows of G, which the inverse transforms as one pair.  Self-paired rows
 // (k1 = 0, M1/2) use A only and carry zeros in the second member of C.
 // ---------------------------------------------------------------------------
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, ASX_ROWS_MIN_WAVES) void k_row
     const AsxDev &P = *Pp; // the rest of the plan constants: device memory, uniform scalar loads
     const int nrows = M1 / 2 + 1;
     float4 *A4 = reinterpret_cast<float4 *>(asx_lds), *B4 = A4 + M2;
-    float *Cf = reinterpret_cast<float *>(asx_lds);
+    float2 *C2 = asx_lds; // the same storage seen as complex values: slot e = C2[2e] (member 0), C2[2e+1]
     __shared__ float2 tw_step[2][ASX_ROW_STEPS];
 
     // one task per block (grid = ntasks)
@@ -334,12 +334,12 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, ASX_ROWS_MIN_WAVES) void k_row
             constexpr int i = decltype(I)::value;
             if (!self) {
                 if (sa[i] >= 0) {
-                    Cf[4 * sa[i] + 0] = gk[i].x; Cf[4 * sa[i] + 2] = gk[i].y;
-                    Cf[4 * sb[i] + 1] = gm[i].x; Cf[4 * sb[i] + 3] = gm[i].y;
+                    C2[2 * sa[i]] = gk[i];       // member 0 of slot sa
+                    C2[2 * sb[i] + 1] = gm[i];   // member 1 of slot sb
                 }
             } else {
-                if (sa[i] >= 0) A4[sa[i]] = make_float4(gk[i].x, 0.f, gk[i].y, 0.f);
-                if (sb[i] >= 0) A4[sb[i]] = make_float4(gm[i].x, 0.f, gm[i].y, 0.f);
+                if (sa[i] >= 0) A4[sa[i]] = make_float4(gk[i].x, gk[i].y, 0.f, 0.f);
+                if (sb[i] >= 0) A4[sb[i]] = make_float4(gm[i].x, gm[i].y, 0.f, 0.f);
             }
         });
         __syncthreads();
@@ -475,7 +475,7 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_inv_cols(const AsxDe
         });
         static_for<0, ASX_COL_LOADS>([&](auto I) __attribute__((always_inline)) {
             const int e = e0 + decltype(I)::value * blockDim.x;
-            if (e < nelem4) lds4[e] = make_float4(v[I].x, v[I].z, v[I].y, v[I].w); // pair-planar
+            if (e < nelem4) lds4[e] = v[I];
         });
     }
     if (threadIdx.x == 0) ncand = 0;
@@ -500,8 +500,8 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_inv_cols(const AsxDe
             const int cg = best_e & (H - 1), j1 = best_e >> logH;
             const uint32_t i0 = 2u * ((uint32_t)j1 * (uint32_t)M2 + (uint32_t)(c0 + 2 * cg));
             const float4 g = lds4[best_e];
-            // lag order inside a slot {re0, re1, im0, im1}: re0, im0, re1, im1
-            const uint32_t h = fabsf(g.x) == best_m ? 0u : fabsf(g.z) == best_m ? 1u : fabsf(g.y) == best_m ? 2u : 3u;
+            // lag order inside a slot = its memory order {re0, im0, re1, im1}
+            const uint32_t h = fabsf(g.x) == best_m ? 0u : fabsf(g.y) == best_m ? 1u : fabsf(g.z) == best_m ? 2u : 3u;
             best = peak_pack_key(best_m, i0 + h);
         }
     } else {
@@ -513,7 +513,7 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_inv_cols(const AsxDe
             if (j2 < M2) {
                 const uint32_t i0 = 2u * ((uint32_t)j1 * (uint32_t)M2 + (uint32_t)j2);
                 const float4 g = lds4[e];
-                const float val[4] = { g.x, g.z, g.y, g.w }; // slot = {re0, re1, im0, im1}
+                const float val[4] = { g.x, g.y, g.z, g.w }; // slot = {re0, im0, re1, im1}: four consecutive lags
 #pragma unroll
                 for (int h = 0; h < 4; h++) {
                     const uint32_t idx = i0 + h;
@@ -544,7 +544,7 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_inv_cols(const AsxDe
         const int j2 = c0 + 2 * cg;
         if (j2 < M2) {
             const uint32_t i0 = 2u * ((uint32_t)j1 * (uint32_t)M2 + (uint32_t)j2);
-            const float val[4] = { g.x, g.z, g.y, g.w }; // slot = {re0, re1, im0, im1}
+            const float val[4] = { g.x, g.y, g.z, g.w }; // slot = {re0, im0, re1, im1}: four consecutive lags
 #pragma unroll
             for (int h = 0; h < 4; h++) {
                 const uint32_t idx = i0 + h;
