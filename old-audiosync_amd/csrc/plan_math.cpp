@@ -147,7 +147,7 @@ std::string asx_host_plan_build(size_t N, const char *split_override, AsxHostPla
     // MI355X, from tools/tune.py (batched float32 path).  Other lengths use the cost model below.
     static const struct { uint32_t M; const char *split; } kTuned[] = {
         { 144000u, "300x480x16" }, { 288000u, "600x480x16" }, { 480000u, "400x1200x16" },
-        { 720000u, "600x1200x16" }, { 960000u, "960x1000x8" }, { 1440000u, "1200x1200x8" },
+        { 720000u, "600x1200x16" }, { 960000u, "800x1200x8" }, { 1440000u, "1200x1200x8" },
     };
     if (!(split_override && *split_override)) {
         for (const auto &t : kTuned)

@@ -32,7 +32,7 @@ for n in lengths:
             d = asx.planmath_describe(n, sp)
         except Exception:
             continue
-        if max(d["radix1"] + d["radix2"]) > 12 or len(d["radix1"]) > 3 or len(d["radix2"]) > 3:
+        if max(d["radix1"] + d["radix2"]) > int(os.environ.get("TUNE_MAXR", "12")) or len(d["radix1"]) > 3 or len(d["radix2"]) > 3:
             continue
         try:
             plan = asx.Plan(n, batch, 0, split=sp)
