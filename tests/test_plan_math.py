@@ -81,3 +81,13 @@ def test_inplace_stage_model_round_trip():
         pos = model.position_table(n, rad)
         assert np.abs(y[pos] - np.fft.fft(x)).max() < 1e-10
         assert np.abs(model.dit_inverse_inplace(y, rad) - n * x).max() < 1e-9
+
+
+def test_unsupported_lengths_are_rejected_with_a_message():
+    mod = asx()
+    for bad in (0, (1 << 27) + 1):
+        with pytest.raises(mod.AsxError):
+            mod.planmath_describe(bad)
+    # a huge prime sample_len embeds into a smooth length that must still split into LDS-sized factors
+    d = mod.planmath_describe(3999971)
+    assert d["F"] >= 3 * 3999971 - 1 and d["M1"] * d["M2"] * 2 == d["F"]
