@@ -6,6 +6,7 @@
 #include "asx_internal.h"
 #include "plan_math.h"
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -66,6 +67,7 @@ struct asx_plan {
     AsxHostPlan host;
     AsxDev dev{};
     size_t group = 1;          // pairs per launch group
+    size_t stamp_blocks = 0;   // diagnostic stamp buffer: blocks x 8 slots
     size_t ws_bytes = 0;
     hipStream_t stream = nullptr;
     std::mutex lock;
@@ -167,11 +169,14 @@ static int plan_init(asx_plan *p, size_t N, size_t max_batch, const char *split)
     }
     HIP_TRY(hipEventCreateWithFlags(&p->fork, hipEventDisableTiming));
     d.stamps = nullptr;
-    if (getenv("ASX_STAMPS")) {
+    d.stamp_kernel = 0;
+    if (const char *e = getenv("ASX_STAMPS")) {
         unsigned long long *st = nullptr;
-        if (dev_alloc(p, &st, g * (size_t)(h.M1 / 2 + 1) * 8)) return -1;
-        HIP_TRY(hipMemset(st, 0, g * (size_t)(h.M1 / 2 + 1) * 8 * sizeof(unsigned long long)));
+        p->stamp_blocks = g * (size_t)std::max(h.M1 / 2 + 1, 2 * h.ntiles);
+        if (dev_alloc(p, &st, p->stamp_blocks * 8)) return -1;
+        HIP_TRY(hipMemset(st, 0, p->stamp_blocks * 8 * sizeof(unsigned long long)));
         d.stamps = st;
+        d.stamp_kernel = !strcmp(e, "fwd") ? 1 : !strcmp(e, "inv") ? 2 : 0;
     }
     {
         AsxDev *dcopy = nullptr;
@@ -242,7 +247,7 @@ extern "C" size_t asx_plan_workspace_bytes(const asx_plan *p) { return p ? p->ws
 extern "C" long asx_plan_debug_stamps(asx_plan *p, unsigned long long *out, size_t cap)
 {
     if (!p || !p->dev.stamps) return -1;
-    size_t n = p->group * (size_t)(p->host.M1 / 2 + 1) * 8;
+    size_t n = p->stamp_blocks * 8;
     if (n > cap) n = cap;
     if (hipMemcpy(out, p->dev.stamps, n * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return -1;
     return (long)n;

@@ -66,7 +66,8 @@ struct AsxDev {
     const int *pos2_of_k2; // k2 -> slot inside a row after the forward row transform
     const int4 *row_tasks; // [M1/2+1] {slot of row k1, slot of row M1-k1, k1, M1-k1}: one load starts a k_rows block
     const AsxDev *self_dev; // device copy of this struct (what the kernels read)
-    unsigned long long *stamps; // diagnostic builds (-DASX_STAMPS) only: per-block phase clocks of k_rows
+    unsigned long long *stamps; // diagnostic builds (-DASX_STAMPS) only: per-block phase clocks, 8 slots per block
+    int stamp_kernel;      // which kernel records them: 0 k_rows, 1 k_fwd_cols, 2 k_inv_cols ($ASX_STAMPS = 1 | fwd | inv)
 };
 
 // Peak-search partial: order-preserving key in the high word, ~index in the low word,

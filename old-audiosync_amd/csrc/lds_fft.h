@@ -12,9 +12,8 @@
 // by the prime-factor maps (no inner twiddles), 8,9,16 by one Cooley-Tukey step in
 // registers with constant inner twiddles,
 // so a length of 800..2000 takes THREE passes over LDS (three barriers) instead
-// of five or six.  The path is VALU-issue bound on gfx950 (one wave64 VALU
-// instruction per 4 cycles per SIMD): two transforms per thread share twiddles and
-// index arithmetic; the floating-point work itself is plain scalar VALU (see v2f).
+// of five or six.  Two transforms per thread share twiddles and index arithmetic; the
+// floating-point work itself is plain scalar VALU (see v2f).
 // Stage twiddles w^(j*u) come from ONE (or two) table reads per butterfly and
 // a short product tree (depth <= 3), not R-1 gathered reads.
 // Index algebra is modelled and tested in tests/model_fourstep.py.
@@ -99,8 +98,11 @@ template <int R, int M> struct Root {
 // {re0, im0, re1, im1}: one ds_read_b128 fills a Cx2.
 // ---------------------------------------------------------------------------
 // Two floats moved together, computed separately.  An ext_vector_type(2) here makes hipcc emit
-// v_pk_add/mul/fma_f32; measured on gfx950 those are an anti-lever (k_rows 2.29 ms packed vs
-// 1.86 ms scalar for the same algebra), so the arithmetic is scalar on purpose and the kernels
+// v_pk_add/mul/fma_f32.  On gfx950 a packed fp32 instruction costs 1.8-2x a scalar one
+// (tools/micro/pk_forms.hip), so packing buys nothing by itself, and packing the two MEMBERS
+// costs shuffles at every LDS access (k_rows 2.29 ms packed vs 1.86 ms scalar for the same
+// algebra); packing re/im instead needs no shuffles and came out even
+// (tools/experiments/packed_aos.patch).  The arithmetic is scalar on purpose and the kernels
 // are built with -fno-slp-vectorize so that LLVM does not re-pack it.
 struct v2f {
     float x, y;

@@ -17,20 +17,22 @@
 #include "asx_internal.h"
 #include "lds_fft.h"
 
+#include <algorithm>
 #include <math.h>
 #include <stdlib.h>
 
 // Diagnostic phase clocks (never in a shipped build; -DASX_STAMPS): lane 0 of every k_rows block
 // records s_memtime at phase boundaries into a buffer nothing else reads.
 #ifdef ASX_STAMPS
-#define ASX_STAMP(slot)                                                                              \
+#define ASX_STAMP_AT(kernel, block, slot)                                                            \
     do {                                                                                             \
-        if (P.stamps && threadIdx.x == 0)                                                            \
-            P.stamps[(size_t)task * 8 + (slot)] = clock64();        \
+        if (P.stamps && P.stamp_kernel == (kernel) && threadIdx.x == 0)                              \
+            P.stamps[(size_t)(block) * 8 + (slot)] = clock64();                                      \
     } while (0)
 #else
-#define ASX_STAMP(slot) do {} while (0)
+#define ASX_STAMP_AT(kernel, block, slot) do {} while (0)
 #endif
+#define ASX_STAMP(slot) ASX_STAMP_AT(0, task, slot)
 
 #ifndef ASX_ROWS_MIN_WAVES
 #define ASX_ROWS_MIN_WAVES 4   // k_rows fits 128 VGPRs (112 with radix 12, scalar arithmetic): four blocks per CU
@@ -101,6 +103,9 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_fwd_cols(const AsxDe
 
     const int nelem4 = M1 << logH;
     const LdsLayout Lc = col_layout(P);
+    const size_t stamp_block = (pair * 2 + blockIdx.y) * P.ntiles + tile;
+    (void)stamp_block;
+    ASX_STAMP_AT(1, stamp_block, 0);
     const TwPre pre = tw_prefetch<true>(P.st1, 0, Lc, P.tw1);
     // all of a thread's tile loads are issued before the first is consumed (ASX_COL_LOADS per
     // round): a rolled loop would pay the HBM latency once per iteration
@@ -147,7 +152,9 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_fwd_cols(const AsxDe
         });
     }
     __syncthreads();
+    ASX_STAMP_AT(1, stamp_block, 1);
     lds_fft<MAXR, false, true>(lds4, P.st1, Lc, P.tw1, pre);
+    ASX_STAMP_AT(1, stamp_block, 2);
 
     // slot p1 holds frequency k1 = k1_of_pos1[p1] and stays in that slot in HBM; the
     // four-step twiddle w_M^(k1*j2) is applied by k_rows, where k1 is block-uniform.
@@ -169,6 +176,7 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_fwd_cols(const AsxDe
             }
         }
     }
+    ASX_STAMP_AT(1, stamp_block, 3);
 }
 
 // ---------------------------------------------------------------------------
@@ -452,6 +460,9 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_inv_cols(const AsxDe
 
     const int nelem4 = M1 << logH;
     const LdsLayout Lc = col_layout(P);
+    const size_t stamp_block = pair * P.ntiles + tile;
+    (void)stamp_block;
+    ASX_STAMP_AT(2, stamp_block, 0);
     const TwPre pre = tw_prefetch<true>(P.st1, P.st1.nstages - 1, Lc, P.tw1);
     for (int e0 = threadIdx.x; e0 < nelem4; e0 += ASX_COL_LOADS * blockDim.x) {
         float4 v[ASX_COL_LOADS];
@@ -480,7 +491,9 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_inv_cols(const AsxDe
     }
     if (threadIdx.x == 0) ncand = 0;
     __syncthreads();
+    ASX_STAMP_AT(2, stamp_block, 1);
     lds_fft<MAXR, true, true>(lds4, P.st1, Lc, P.tw1, pre);
+    ASX_STAMP_AT(2, stamp_block, 2);
 
     // Peak search.  A thread meets its lags in increasing order, so a strict '>' keeps the
     // earliest of equal keys, like the reference's sequential scan (src/cross_correlation.c:60).
@@ -488,6 +501,7 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_inv_cols(const AsxDe
     // not in it and r is not being dumped -> two packed max per slot, indices resolved at the end.
     const bool fast = even && (c0 + T <= M2) && (P.nout == P.F) && (tile != 0) && (r_out == nullptr);
     asx_peak_t best = 0;
+    float thread_max = -INFINITY; // fast path: the largest |r| this thread has seen
     if (fast) {
         float best_m = -INFINITY;
         int best_e = -1;
@@ -496,6 +510,7 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_inv_cols(const AsxDe
             const float m = fmaxf(fmaxf(fabsf(g.x), fabsf(g.y)), fmaxf(fabsf(g.z), fabsf(g.w))); // NaNs drop out
             if (m > best_m) { best_m = m; best_e = e; }
         }
+        thread_max = best_m;
         if (best_e >= 0) {
             const int cg = best_e & (H - 1), j1 = best_e >> logH;
             const uint32_t i0 = 2u * ((uint32_t)j1 * (uint32_t)M2 + (uint32_t)(c0 + 2 * cg));
@@ -534,7 +549,9 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_inv_cols(const AsxDe
     // second look at the tile (still in LDS): lags as large as the tile maximum within
     // float32 accuracy.  A lag near the GLOBAL maximum is necessarily near its tile's maximum.
     const float thr = near_max_threshold(peak_key(tile_best));
-    for (int e = threadIdx.x; e < nelem4; e += blockDim.x) {
+    // fast path: a thread whose own maximum is below the threshold (almost every thread) has nothing to add
+    const bool look = !fast || thread_max >= thr;
+    for (int e = threadIdx.x; look && e < nelem4; e += blockDim.x) {
         const float4 g = lds4[e];
         if (fast) {
             const float m = fmaxf(fmaxf(fabsf(g.x), fabsf(g.y)), fmaxf(fabsf(g.z), fabsf(g.w)));
@@ -565,6 +582,7 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_inv_cols(const AsxDe
         W.cand_n[t] = ncand;
     }
     if (threadIdx.x < ASX_CAND_TILE && threadIdx.x < ncand) W.cand[t * ASX_CAND_TILE + threadIdx.x] = lcand[threadIdx.x];
+    ASX_STAMP_AT(2, stamp_block, 3);
 }
 
 // ---------------------------------------------------------------------------
@@ -907,7 +925,9 @@ void asx_launch_rows(const AsxDev &P, const float2 *zxa, const float2 *zya, floa
                      hipStream_t s)
 {
     const int ntasks = (P.M1 / 2 + 1) * npairs;
-    const size_t lds = asx_lds_bytes_rows(P);
+    size_t lds = asx_lds_bytes_rows(P);
+    // diagnostic: a larger request caps the blocks per CU (occupancy sweep, tools/README.md)
+    if (const char *e = getenv("ASX_DBG_ROWS_LDS")) lds = std::max(lds, (size_t)atol(e));
 #define ASX_LAUNCH(MAXR) \
     do { allow_big_lds((const void *)k_rows<MAXR>, lds); \
          int grid = ntasks; /* one task (pair, k1) per block */ \

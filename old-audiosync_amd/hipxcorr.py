@@ -209,10 +209,11 @@ class Stream:
         self._h = lib().asx_stream_create(int(max_sample_len), int(device))
         if not self._h:
             raise AsxError(_err())
+        self._destroy = lib().asx_stream_destroy  # bound now: module globals may be gone at interpreter exit
 
     def close(self):
         if getattr(self, "_h", None):
-            lib().asx_stream_destroy(self._h)
+            self._destroy(self._h)
             self._h = None
 
     __del__ = close
@@ -247,11 +248,12 @@ class Plan:
                                            _split_arg(split))
         if not self._h:
             raise AsxError(_err())
+        self._destroy = lib().asx_plan_destroy  # bound now: module globals may be gone at interpreter exit
         self.sample_len = int(sample_len)
 
     def close(self):
         if getattr(self, "_h", None):
-            lib().asx_plan_destroy(self._h)
+            self._destroy(self._h)
             self._h = None
 
     __del__ = close
