@@ -1,4 +1,8 @@
 // csrc/plan_math.cpp — see plan_math.h.  Pure host arithmetic.
+#include <cstring>
+#include <cstdlib>
+#include <functional>
+#include <algorithm>
 #include "plan_math.h"
 
 #include <cmath>
@@ -59,6 +63,12 @@ bool asx_make_stages(int n, AsxStages *st)
     std::vector<int> order;
     for (int i = 0; i < best_depth; i++) if (best[i] % 2 == 0) order.push_back(best[i]);
     for (int i = 0; i < best_depth; i++) if (best[i] % 2 != 0) order.push_back(best[i]);
+    // diagnostic: other orders of the same radices ([10,10,12] does fewer twiddle
+    // multiplications than [12,10,10] but its innermost stage strides 12 slots = 4-way bank conflicts, +17 % k_rows)
+    if (const char *e = getenv("ASX_STAGE_ORDER")) {
+        if (!strcmp(e, "asc")) std::sort(order.begin(), order.end());
+        else if (!strcmp(e, "desc")) std::sort(order.begin(), order.end(), std::greater<int>());
+    }
     int ns = n;
     for (int i = 0; i < (int)order.size(); i++) {
         const int R = order[i];
