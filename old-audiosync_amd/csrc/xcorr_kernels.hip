@@ -423,6 +423,23 @@ __device__ __forceinline__ asx_peak_t block_peak_max(asx_peak_t v, asx_peak_t *s
     return v;
 }
 
+// Wave-wide maximum of non-negative floats without LDS traffic: four DPP steps leave every lane of
+// a 16-lane row with the row's maximum, three readlanes combine the rows.  (__shfl_xor goes through
+// ds_bpermute: one LDS round trip per step.)
+__device__ __forceinline__ float wave_max_nonneg(float v)
+{
+#define ASX_DPP_MAX(ctrl) v = fmaxf(v, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), (ctrl), 0xF, 0xF, true)))
+    ASX_DPP_MAX(0xB1);  // quad_perm [1,0,3,2]
+    ASX_DPP_MAX(0x4E);  // quad_perm [2,3,0,1]
+    ASX_DPP_MAX(0x141); // row_half_mirror
+    ASX_DPP_MAX(0x140); // row_mirror
+#undef ASX_DPP_MAX
+    const int b = __float_as_int(v);
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(b, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(b, 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(b, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(b, 48));
+    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
+
 // ---------------------------------------------------------------------------
 // k_inv_cols: grid (ntiles, npairs).  Inverse column transforms; the time-domain
 // correlation r[2j] = Re g[j], r[2j+1] = Im g[j] only lives in LDS/registers.
@@ -500,26 +517,77 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_inv_cols(const AsxDe
     // Fast path (block-uniform): the tile is full, every lag counts, lag 0 (the signed one) is
     // not in it and r is not being dumped -> two packed max per slot, indices resolved at the end.
     const bool fast = even && (c0 + T <= M2) && (P.nout == P.F) && (tile != 0) && (r_out == nullptr);
-    asx_peak_t best = 0;
-    float thread_max = -INFINITY; // fast path: the largest |r| this thread has seen
+    // one candidate test per lag of a slot (second look below)
+    auto examine_slot = [&](int e, float4 g, float thr) {
+        const int cg = e & (H - 1), j1 = e >> logH;
+        const int j2 = c0 + 2 * cg;
+        if (j2 >= M2) return;
+        const uint32_t i0 = 2u * ((uint32_t)j1 * (uint32_t)M2 + (uint32_t)j2);
+        const float val[4] = { g.x, g.y, g.z, g.w }; // slot = {re0, im0, re1, im1}: four consecutive lags
+#pragma unroll
+        for (int h = 0; h < 4; h++) {
+            const uint32_t idx = i0 + h;
+            if (idx < P.nout && j2 + (h >> 1) < M2) {
+                const float key = peak_key_of(val[h], idx);
+                if (key >= thr) {
+                    const uint32_t slot = atomicAdd(&ncand, 1u);
+                    if (slot < ASX_CAND_TILE) { lcand[slot].idx = idx; lcand[slot].key = key; }
+                }
+            }
+        }
+    };
     if (fast) {
-        float best_m = -INFINITY;
-        int best_e = -1;
+        // pass 1: per thread the largest and second largest slot maximum
+        float best_m = -INFINITY, second_m = -INFINITY;
+        int best_e = threadIdx.x;
         for (int e = threadIdx.x; e < nelem4; e += blockDim.x) {
             const float4 g = lds4[e];
             const float m = fmaxf(fmaxf(fabsf(g.x), fabsf(g.y)), fmaxf(fabsf(g.z), fabsf(g.w))); // NaNs drop out
-            if (m > best_m) { best_m = m; best_e = e; }
+            if (m > best_m) { second_m = best_m; best_m = m; best_e = e; }
+            else if (m > second_m) second_m = m;
         }
-        thread_max = best_m;
-        if (best_e >= 0) {
+        const float4 gb = lds4[best_e];
+        uint32_t my_idx;
+        {
             const int cg = best_e & (H - 1), j1 = best_e >> logH;
             const uint32_t i0 = 2u * ((uint32_t)j1 * (uint32_t)M2 + (uint32_t)(c0 + 2 * cg));
-            const float4 g = lds4[best_e];
             // lag order inside a slot = its memory order {re0, im0, re1, im1}
-            const uint32_t h = fabsf(g.x) == best_m ? 0u : fabsf(g.y) == best_m ? 1u : fabsf(g.z) == best_m ? 2u : 3u;
-            best = peak_pack_key(best_m, i0 + h);
+            const uint32_t h = fabsf(gb.x) == best_m ? 0u : fabsf(gb.y) == best_m ? 1u : fabsf(gb.z) == best_m ? 2u : 3u;
+            my_idx = i0 + h;
+        }
+        // wave maximum in registers, smallest lag among the lanes that hold it, one entry per wave
+        const float wmax = wave_max_nonneg(fmaxf(best_m, 0.f));
+        unsigned long long holders = __ballot(best_m == wmax);
+        uint32_t widx = 0xFFFFFFFFu;
+        while (holders) {
+            const int l = __ffsll((long long)holders) - 1;
+            const uint32_t li = (uint32_t)__builtin_amdgcn_readlane((int)my_idx, l);
+            widx = li < widx ? li : widx;
+            holders &= holders - 1;
+        }
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = widx == 0xFFFFFFFFu ? 0 : peak_pack_key(wmax, widx);
+        __syncthreads();
+        // every thread folds the wave entries itself: no second barrier to broadcast the result
+        asx_peak_t tb = red[0];
+        for (int w = 1; w < (int)((blockDim.x + 63) >> 6); w++) tb = peak_max(tb, red[w]);
+        if (threadIdx.x == 0) tile_best = tb;
+        // second look at the tile (still in LDS): lags as large as the tile maximum within float32
+        // accuracy.  Almost every thread is below the threshold; the one that holds the maximum
+        // usually has no second slot near it and examines just that slot.
+        const float thr = near_max_threshold(peak_key(tb));
+        if (best_m >= thr) {
+            if (second_m >= thr) {
+                for (int e = threadIdx.x; e < nelem4; e += blockDim.x) {
+                    const float4 g = lds4[e];
+                    const float m = fmaxf(fmaxf(fabsf(g.x), fabsf(g.y)), fmaxf(fabsf(g.z), fabsf(g.w)));
+                    if (m >= thr) examine_slot(e, g, thr);
+                }
+            } else {
+                examine_slot(best_e, gb, thr);
+            }
         }
     } else {
+        asx_peak_t best = 0;
         float best_key = -INFINITY;
         uint32_t best_idx = 0xFFFFFFFFu;
         for (int e = threadIdx.x; e < nelem4; e += blockDim.x) {
@@ -541,39 +609,13 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_inv_cols(const AsxDe
             }
         }
         best = best_idx == 0xFFFFFFFFu ? 0 : peak_pack_key(best_key, best_idx);
-    }
-    best = block_peak_max(best, red);
-    if (threadIdx.x == 0) tile_best = best;
-    __syncthreads();
-
-    // second look at the tile (still in LDS): lags as large as the tile maximum within
-    // float32 accuracy.  A lag near the GLOBAL maximum is necessarily near its tile's maximum.
-    const float thr = near_max_threshold(peak_key(tile_best));
-    // fast path: a thread whose own maximum is below the threshold (almost every thread) has nothing to add
-    const bool look = !fast || thread_max >= thr;
-    for (int e = threadIdx.x; look && e < nelem4; e += blockDim.x) {
-        const float4 g = lds4[e];
-        if (fast) {
-            const float m = fmaxf(fmaxf(fabsf(g.x), fabsf(g.y)), fmaxf(fabsf(g.z), fabsf(g.w)));
-            if (!(m >= thr)) continue; // almost every slot
-        }
-        const int cg = e & (H - 1), j1 = e >> logH;
-        const int j2 = c0 + 2 * cg;
-        if (j2 < M2) {
-            const uint32_t i0 = 2u * ((uint32_t)j1 * (uint32_t)M2 + (uint32_t)j2);
-            const float val[4] = { g.x, g.y, g.z, g.w }; // slot = {re0, im0, re1, im1}: four consecutive lags
-#pragma unroll
-            for (int h = 0; h < 4; h++) {
-                const uint32_t idx = i0 + h;
-                if (idx < P.nout && j2 + (h >> 1) < M2) {
-                    const float key = peak_key_of(val[h], idx);
-                    if (key >= thr) {
-                        const uint32_t slot = atomicAdd(&ncand, 1u);
-                        if (slot < ASX_CAND_TILE) { lcand[slot].idx = idx; lcand[slot].key = key; }
-                    }
-                }
-            }
-        }
+        best = block_peak_max(best, red);
+        if (threadIdx.x == 0) tile_best = best;
+        __syncthreads();
+        // second look at the tile (still in LDS): lags as large as the tile maximum within
+        // float32 accuracy.  A lag near the GLOBAL maximum is necessarily near its tile's maximum.
+        const float thr = near_max_threshold(peak_key(tile_best));
+        for (int e = threadIdx.x; e < nelem4; e += blockDim.x) examine_slot(e, lds4[e], thr);
     }
     __syncthreads();
     const size_t t = pair * (size_t)P.ntiles + tile;
