@@ -319,26 +319,73 @@ struct TwPre {
     float2 w1, w4;
 };
 
+// Geometry of one DIF stage, passed BY VALUE.  From a runtime schedule it is seven loads from the
+// plan; from a compile-time schedule (Sched below) it is seven literals, and since every stage
+// function is force-inlined the compiler folds them: no scalar loads, no radix switch, divisions
+// by constants, and the R slot offsets of a butterfly become immediate offsets of the LDS
+// instructions.  The production lengths run on such specialised instantiations (xcorr_kernels.hip).
+struct StageK {
+    int R, ns, q, nbf, twmul;
+    float inv_q, inv_nbf;
+};
+__device__ __forceinline__ StageK stage_k(const AsxStages &st, int i)
+{
+    return StageK{ st.radix[i], st.ns[i], st.q[i], st.nbf[i], st.twmul[i], st.inv_q[i], st.inv_nbf[i] };
+}
+// compile-time schedule of an n-point transform: radices of the DIF stages in order
+template <int N, int... Rs> struct Sched {
+    static constexpr int n = N;
+    static constexpr int nstages = (int)sizeof...(Rs);
+    static constexpr int radix(int i)
+    {
+        constexpr int r[] = { Rs... };
+        return r[i];
+    }
+    static constexpr int max_radix()
+    {
+        int m = 2;
+        for (int i = 0; i < nstages; i++) m = radix(i) > m ? radix(i) : m;
+        return m;
+    }
+    static constexpr StageK stage(int i)
+    {
+        int ns = N;
+        for (int j = 0; j < i; j++) ns /= radix(j);
+        const int R = radix(i), q = ns / R, nbf = N / R;
+        return StageK{ R, ns, q, nbf, N / ns, 1.0f / (float)q, 1.0f / (float)nbf };
+    }
+};
+
 template <bool GFAST>
-__device__ __forceinline__ TwPre tw_prefetch(const AsxStages &st, int i, const LdsLayout &L,
-                                             const float2 *__restrict__ tw)
+__device__ __forceinline__ TwPre tw_prefetch_k(const StageK K, const LdsLayout &L, const float2 *__restrict__ tw)
 {
     TwPre pre;
     pre.w1 = make_float2(1.f, 0.f);
     pre.w4 = make_float2(1.f, 0.f);
-    if (i < 0 || i >= st.nstages) return pre;
-    const int q = st.q[i], nbf = st.nbf[i];
     const int w = threadIdx.x;
-    if (q == 1 || w >= L.ngroups * nbf) return pre;
+    if (K.q == 1 || w >= L.ngroups * K.nbf) return pre;
     int bf;
     if (GFAST) bf = w >> L.log_ngroups;
-    else (void)div_exact(w, nbf, st.inv_nbf[i], bf);
+    else (void)div_exact(w, K.nbf, K.inv_nbf, bf);
     int j;
-    (void)div_exact(bf, q, st.inv_q[i], j);
-    const int tj = j * st.twmul[i];
+    (void)div_exact(bf, K.q, K.inv_q, j);
+    const int tj = j * K.twmul;
     pre.w1 = tw[tj];
-    if (st.radix[i] > 4) pre.w4 = tw[4 * tj];
+    if (K.R > 4) pre.w4 = tw[4 * tj];
     return pre;
+}
+template <bool GFAST>
+__device__ __forceinline__ TwPre tw_prefetch(const AsxStages &st, int i, const LdsLayout &L,
+                                             const float2 *__restrict__ tw)
+{
+    if (i < 0 || i >= st.nstages) return TwPre{ make_float2(1.f, 0.f), make_float2(1.f, 0.f) };
+    return tw_prefetch_k<GFAST>(stage_k(st, i), L, tw);
+}
+// first stage to run of a compile-time schedule
+template <class S, bool INV, bool GFAST>
+__device__ __forceinline__ TwPre tw_prefetch_first(const LdsLayout &L, const float2 *__restrict__ tw)
+{
+    return tw_prefetch_k<GFAST>(S::stage(INV ? S::nstages - 1 : 0), L, tw);
 }
 
 // Stage twiddles from (W^1, W^4): products of depth <= 3
@@ -361,11 +408,11 @@ template <int R> __device__ __forceinline__ void stage_twiddles_from(float2 w1, 
 }
 
 template <int R, bool INV, bool GFAST, bool UNIT_TW>
-__device__ __forceinline__ void lds_stage(float4 *lds, const AsxStages &st, int i, const LdsLayout &L,
+__device__ __forceinline__ void lds_stage(float4 *lds, const StageK K, const LdsLayout &L,
                                           const float2 *__restrict__ tw, TwPre pre)
 {
-    const int ns = st.ns[i], q = st.q[i], nbf = st.nbf[i], twmul = st.twmul[i];
-    const float inv_q = st.inv_q[i], inv_nbf = st.inv_nbf[i];
+    const int ns = K.ns, q = K.q, nbf = K.nbf, twmul = K.twmul;
+    const float inv_q = K.inv_q, inv_nbf = K.inv_nbf;
     const int total = L.ngroups * nbf;
     const int step = q * L.elem_stride;
     for (int w = threadIdx.x; w < total; w += blockDim.x) {
@@ -407,24 +454,24 @@ __device__ __forceinline__ void lds_stage(float4 *lds, const AsxStages &st, int 
 }
 
 template <int R, bool INV, bool GFAST>
-__device__ __forceinline__ void lds_stage_r(float4 *lds, const AsxStages &st, int i, const LdsLayout &L,
+__device__ __forceinline__ void lds_stage_r(float4 *lds, const StageK K, const LdsLayout &L,
                                             const float2 *__restrict__ tw, TwPre pre)
 {
-    if (st.q[i] == 1) // wave-uniform
-        lds_stage<R, INV, GFAST, true>(lds, st, i, L, tw, pre);
+    if (K.q == 1) // wave-uniform
+        lds_stage<R, INV, GFAST, true>(lds, K, L, tw, pre);
     else
-        lds_stage<R, INV, GFAST, false>(lds, st, i, L, tw, pre);
+        lds_stage<R, INV, GFAST, false>(lds, K, L, tw, pre);
 }
 
 // MAXR: largest radix this kernel variant carries code for.  Register allocation is per
 // kernel, so a variant without the radix-15/16 bodies keeps the occupancy of the small ones.
 template <int MAXR, bool INV, bool GFAST>
-__device__ __forceinline__ void lds_stage_any(float4 *lds, const AsxStages &st, int i, const LdsLayout &L,
+__device__ __forceinline__ void lds_stage_any(float4 *lds, const StageK K, const LdsLayout &L,
                                               const float2 *__restrict__ tw, TwPre pre)
 {
 #define ASX_STAGE_CASE(R) \
-    case R: if constexpr (R <= MAXR) lds_stage_r<R, INV, GFAST>(lds, st, i, L, tw, pre); break;
-    switch (st.radix[i]) { // wave-uniform
+    case R: if constexpr (R <= MAXR) lds_stage_r<R, INV, GFAST>(lds, K, L, tw, pre); break;
+    switch (K.R) { // wave-uniform
         ASX_STAGE_CASE(16)
         ASX_STAGE_CASE(15)
         ASX_STAGE_CASE(12)
@@ -435,7 +482,7 @@ __device__ __forceinline__ void lds_stage_any(float4 *lds, const AsxStages &st, 
         ASX_STAGE_CASE(5)
         ASX_STAGE_CASE(4)
         ASX_STAGE_CASE(3)
-    default: lds_stage_r<2, INV, GFAST>(lds, st, i, L, tw, pre); break;
+    default: lds_stage_r<2, INV, GFAST>(lds, K, L, tw, pre); break;
     }
 #undef ASX_STAGE_CASE
 }
@@ -451,16 +498,33 @@ __device__ __forceinline__ void lds_fft(float4 *lds, const AsxStages &st, const 
     if (!INV) {
         for (int i = 0; i < st.nstages; i++) {
             const TwPre next = tw_prefetch<GFAST>(st, i + 1, L, tw);
-            lds_stage_any<MAXR, false, GFAST>(lds, st, i, L, tw, pre);
+            lds_stage_any<MAXR, false, GFAST>(lds, stage_k(st, i), L, tw, pre);
             pre = next;
             __syncthreads();
         }
     } else {
         for (int i = st.nstages - 1; i >= 0; i--) {
             const TwPre next = tw_prefetch<GFAST>(st, i - 1, L, tw);
-            lds_stage_any<MAXR, true, GFAST>(lds, st, i, L, tw, pre);
+            lds_stage_any<MAXR, true, GFAST>(lds, stage_k(st, i), L, tw, pre);
             pre = next;
             __syncthreads();
         }
     }
+}
+
+// The same with a compile-time schedule S = Sched<n, radices...>: the stage loop is unrolled and
+// every stage is instantiated for its own radix and geometry only.
+template <class S, bool INV, bool GFAST>
+__device__ __forceinline__ void lds_fft_static(float4 *lds, const LdsLayout &L, const float2 *__restrict__ tw, TwPre pre)
+{
+    static_for<0, S::nstages>([&](auto I) __attribute__((always_inline)) {
+        constexpr int i = INV ? S::nstages - 1 - decltype(I)::value : decltype(I)::value;
+        constexpr int inext = INV ? i - 1 : i + 1;
+        constexpr StageK K = S::stage(i);
+        TwPre next{ make_float2(1.f, 0.f), make_float2(1.f, 0.f) };
+        if constexpr (inext >= 0 && inext < S::nstages) next = tw_prefetch_k<GFAST>(S::stage(inext), L, tw);
+        lds_stage<K.R, INV, GFAST, K.q == 1>(lds, K, L, tw, pre);
+        pre = next;
+        __syncthreads();
+    });
 }

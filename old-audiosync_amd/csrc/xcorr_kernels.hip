@@ -18,7 +18,9 @@
 #include "lds_fft.h"
 
 #include <algorithm>
+#include <initializer_list>
 #include <math.h>
+#include <type_traits>
 #include <stdlib.h>
 
 // Diagnostic phase clocks (never in a shipped build; -DASX_STAMPS): lane 0 of every k_rows block
@@ -65,20 +67,23 @@ __device__ __forceinline__ int col_tile_of_block(int b)
     return (b & ~15) + 2 * (b & 7) + ((b >> 3) & 1);
 }
 
-__device__ __forceinline__ LdsLayout col_layout(const AsxDev &P)
+__device__ __forceinline__ LdsLayout col_layout(int T, int logT)
 {
     LdsLayout L;
-    L.ngroups = P.T >> 1;
-    L.log_ngroups = P.logT - 1;
-    L.elem_stride = P.T >> 1;
+    L.ngroups = T >> 1;
+    L.log_ngroups = logT - 1;
+    L.elem_stride = T >> 1;
     L.group_stride = 1;
     return L;
 }
+constexpr int asx_ilog2(int v) { return v <= 1 ? 0 : 1 + asx_ilog2(v >> 1); }
 
 // k_fwd_cols: grid (ntiles, 2, npairs).  blockIdx.y: 0 = source, 1 = sample.
 // Packs real samples as complex (z[j] = x[2j] + i x[2j+1]); zero padding and the periodic
 // extension of the source (embedded lengths) happen in the loads, never in HBM.
-template <int MAXR>
+// S1 = void, TC = 0: column schedule and tile width from the plan at run time (any length);
+// S1 = Sched<M1, radices...>, TC = tile width: compiled in (production lengths, see the launchers).
+template <int MAXR, class S1 = void, int TC = 0>
 __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_fwd_cols(const AsxDev *__restrict__ Pp,
                                                                       const float *__restrict__ src,
                                                                       const float *__restrict__ smp,
@@ -90,7 +95,10 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_fwd_cols(const AsxDe
     if (tile >= P.ntiles) return; // grid.x is rounded up to a multiple of 16
     const bool is_smp = blockIdx.y != 0;
     const size_t pair = blockIdx.z;
-    const int T = P.T, logH = P.logT - 1, H = T >> 1, M1 = P.M1, M2 = P.M2;
+    constexpr bool STATIC = !std::is_void<S1>::value;
+    int T = P.T, logT = P.logT, M1 = P.M1;
+    if constexpr (STATIC) { T = TC; logT = asx_ilog2(TC); M1 = S1::n; }
+    const int logH = logT - 1, H = T >> 1, M2 = P.M2;
     const int c0 = tile * T;
 
     const float *in = is_smp ? smp + pair * (size_t)P.N : src + pair * (size_t)P.src_period;
@@ -102,11 +110,13 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_fwd_cols(const AsxDe
     float4 *lds4 = reinterpret_cast<float4 *>(asx_lds);
 
     const int nelem4 = M1 << logH;
-    const LdsLayout Lc = col_layout(P);
+    const LdsLayout Lc = col_layout(T, logT);
     const size_t stamp_block = (pair * 2 + blockIdx.y) * P.ntiles + tile;
     (void)stamp_block;
     ASX_STAMP_AT(1, stamp_block, 0);
-    const TwPre pre = tw_prefetch<true>(P.st1, 0, Lc, P.tw1);
+    TwPre pre;
+    if constexpr (STATIC) pre = tw_prefetch_first<S1, false, true>(Lc, P.tw1);
+    else pre = tw_prefetch<true>(P.st1, 0, Lc, P.tw1);
     // all of a thread's tile loads are issued before the first is consumed (ASX_COL_LOADS per
     // round): a rolled loop would pay the HBM latency once per iteration
     // Fast path (block-uniform): full tile, 16-byte aligned rows, no periodic extension, and the
@@ -153,7 +163,8 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_fwd_cols(const AsxDe
     }
     __syncthreads();
     ASX_STAMP_AT(1, stamp_block, 1);
-    lds_fft<MAXR, false, true>(lds4, P.st1, Lc, P.tw1, pre);
+    if constexpr (STATIC) lds_fft_static<S1, false, true>(lds4, Lc, P.tw1, pre);
+    else lds_fft<MAXR, false, true>(lds4, P.st1, Lc, P.tw1, pre);
     ASX_STAMP_AT(1, stamp_block, 2);
 
     // slot p1 holds frequency k1 = k1_of_pos1[p1] and stays in that slot in HBM; the
@@ -214,14 +225,19 @@ struct RowRegs {
     float2 xa[ASX_ROW_STEPS], ya[ASX_ROW_STEPS], xb[ASX_ROW_STEPS], yb[ASX_ROW_STEPS];
 };
 
-template <int MAXR>
+// S2 = void: schedule of the row transforms read from the plan at run time (any length);
+// S2 = Sched<M2, radices...>: compiled in (the production lengths, see asx_launch_rows).
+template <int MAXR, class S2 = void>
 __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, ASX_ROWS_MIN_WAVES) void k_rows(const AsxDev *__restrict__ Pp,
                                                                   const float2 *__restrict__ zxa,
                                                                   const float2 *__restrict__ zya,
                                                                   float2 *__restrict__ ga,
                                                                   const int4 *__restrict__ row_tasks,
-                                                                  int M1, int M2, uint32_t M)
+                                                                  int M1, int M2_arg, uint32_t M)
 {
+    constexpr bool STATIC = !std::is_void<S2>::value;
+    int M2 = M2_arg;
+    if constexpr (STATIC) M2 = S2::n;
     // The start of a block is a chain of dependent memory accesses (plan struct -> index table ->
     // rows); M1/M2/M and the task table come as kernel arguments so that ONE 16-byte load
     // (slots and row numbers) separates the block from its row loads.
@@ -262,7 +278,9 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, ASX_ROWS_MIN_WAVES) void k_row
                 }
             });
         }
-        const TwPre pre_f = tw_prefetch<false>(P.st2, 0, Lf, P.tw2);
+        TwPre pre_f;
+        if constexpr (STATIC) pre_f = tw_prefetch_first<S2, false, false>(Lf, P.tw2);
+        else pre_f = tw_prefetch<false>(P.st2, 0, Lf, P.tw2);
 
         // Four-step twiddle of row k1: w_M^(k1*j2) with j2 = t + blockDim*i factors into
         // w_M^(k1*t) (one two-level lookup per thread) times w_M^(k1*blockDim*i) (a handful per block).
@@ -292,7 +310,8 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, ASX_ROWS_MIN_WAVES) void k_row
         }
         __syncthreads();
         ASX_STAMP(1);
-        lds_fft<MAXR, false, false>(A4, P.st2, Lf, P.tw2, pre_f);
+        if constexpr (STATIC) lds_fft_static<S2, false, false>(A4, Lf, P.tw2, pre_f);
+        else lds_fft<MAXR, false, false>(A4, P.st2, Lf, P.tw2, pre_f);
         ASX_STAMP(2);
 
         // ---- spectral combine.  Every thread first computes its G values into registers (it
@@ -336,7 +355,9 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, ASX_ROWS_MIN_WAVES) void k_row
                 }
             }
         });
-        const TwPre pre_i = tw_prefetch<false>(P.st2, P.st2.nstages - 1, Li, P.tw2);
+        TwPre pre_i;
+        if constexpr (STATIC) pre_i = tw_prefetch_first<S2, true, false>(Li, P.tw2);
+        else pre_i = tw_prefetch<false>(P.st2, P.st2.nstages - 1, Li, P.tw2);
         __syncthreads();
         static_for<0, ASX_ROW_STEPS>([&](auto I) __attribute__((always_inline)) {
             constexpr int i = decltype(I)::value;
@@ -354,7 +375,8 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, ASX_ROWS_MIN_WAVES) void k_row
 
         ASX_STAMP(3);
         // inverse row transforms of the G pair, digit-reversed in -> natural j2 out
-        lds_fft<MAXR, true, false>(A4, P.st2, Li, P.tw2, pre_i);
+        if constexpr (STATIC) lds_fft_static<S2, true, false>(A4, Li, P.tw2, pre_i);
+        else lds_fft<MAXR, true, false>(A4, P.st2, Li, P.tw2, pre_i);
         ASX_STAMP(4);
 
         // inverse four-step twiddle conj(w_M^(k1*j2)) / conj(w_M^(m1*j2)), one per member
@@ -457,7 +479,7 @@ __device__ __forceinline__ float near_max_threshold(float kmax)
     return kmax > 0.f ? kmax * (1.0f - ASX_REFINE_EPS) : kmax;
 }
 
-template <int MAXR>
+template <int MAXR, class S1 = void, int TC = 0>
 __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_inv_cols(const AsxDev *__restrict__ Pp, const float2 *__restrict__ ga,
                                                                    AsxPeakWs W, float *__restrict__ r_out)
 {
@@ -469,18 +491,23 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_inv_cols(const AsxDe
     const int tile = col_tile_of_block(blockIdx.x);
     if (tile >= P.ntiles) return; // grid.x is rounded up to a multiple of 16
     const size_t pair = blockIdx.y;
-    const int T = P.T, logH = P.logT - 1, H = T >> 1, M1 = P.M1, M2 = P.M2;
+    constexpr bool STATIC = !std::is_void<S1>::value;
+    int T = P.T, logT = P.logT, M1 = P.M1;
+    if constexpr (STATIC) { T = TC; logT = asx_ilog2(TC); M1 = S1::n; }
+    const int logH = logT - 1, H = T >> 1, M2 = P.M2;
     const int c0 = tile * T;
     const float2 *in = ga + pair * (size_t)P.M;
     const bool even = (M2 & 1) == 0;
     float4 *lds4 = reinterpret_cast<float4 *>(asx_lds);
 
     const int nelem4 = M1 << logH;
-    const LdsLayout Lc = col_layout(P);
+    const LdsLayout Lc = col_layout(T, logT);
     const size_t stamp_block = pair * P.ntiles + tile;
     (void)stamp_block;
     ASX_STAMP_AT(2, stamp_block, 0);
-    const TwPre pre = tw_prefetch<true>(P.st1, P.st1.nstages - 1, Lc, P.tw1);
+    TwPre pre;
+    if constexpr (STATIC) pre = tw_prefetch_first<S1, true, true>(Lc, P.tw1);
+    else pre = tw_prefetch<true>(P.st1, P.st1.nstages - 1, Lc, P.tw1);
     for (int e0 = threadIdx.x; e0 < nelem4; e0 += ASX_COL_LOADS * blockDim.x) {
         float4 v[ASX_COL_LOADS];
         static_for<0, ASX_COL_LOADS>([&](auto I) __attribute__((always_inline)) {
@@ -509,7 +536,8 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_inv_cols(const AsxDe
     if (threadIdx.x == 0) ncand = 0;
     __syncthreads();
     ASX_STAMP_AT(2, stamp_block, 1);
-    lds_fft<MAXR, true, true>(lds4, P.st1, Lc, P.tw1, pre);
+    if constexpr (STATIC) lds_fft_static<S1, true, true>(lds4, Lc, P.tw1, pre);
+    else lds_fft<MAXR, true, true>(lds4, P.st1, Lc, P.tw1, pre);
     ASX_STAMP_AT(2, stamp_block, 2);
 
     // Peak search.  A thread meets its lags in increasing order, so a strict '>' keeps the
@@ -951,13 +979,35 @@ static void allow_big_lds(const void *fn, size_t bytes)
     if (bytes > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
+static bool schedule_is(const AsxStages &st, int n, std::initializer_list<int> radices)
+{
+    if (st.n != n || st.nstages != (int)radices.size()) return false;
+    int i = 0;
+    for (int r : radices)
+        if (st.radix[i++] != r) return false;
+    return true;
+}
+static bool generic_only()
+{
+    static const bool g = getenv("ASX_GENERIC") != nullptr; // diagnostic: never use the compiled-in schedules
+    return g;
+}
+// Column schedules of the production sample lengths (plan_math.cpp's tuned table), compiled in:
+//   X(M1, tile width, MAXR for the launch bounds, radices...)
+#define ASX_STATIC_COLS(X) \
+    X(1200, 8, 12, 12, 10, 10) X(800, 8, 10, 10, 10, 8) X(600, 16, 10, 10, 10, 6) X(400, 16, 10, 10, 8, 5) X(300, 16, 10, 10, 6, 5)
+
 void asx_launch_fwd_cols(const AsxDev &P, const float *src, const float *smp, float2 *zxa,
                          float2 *zya, int npairs, hipStream_t s)
 {
     dim3 grid((P.ntiles + 15) / 16 * 16, 2, npairs);
-#define ASX_LAUNCH(MAXR) \
-    do { allow_big_lds((const void *)k_fwd_cols<MAXR>, asx_lds_bytes_cols(P)); \
-         hipLaunchKernelGGL(k_fwd_cols<MAXR>, grid, dim3(P.threads_cols), asx_lds_bytes_cols(P), s, P.self_dev, src, smp, zxa, zya); } while (0)
+#define ASX_LAUNCH(...) \
+    do { allow_big_lds((const void *)k_fwd_cols<__VA_ARGS__>, asx_lds_bytes_cols(P)); \
+         hipLaunchKernelGGL((k_fwd_cols<__VA_ARGS__>), grid, dim3(P.threads_cols), asx_lds_bytes_cols(P), s, P.self_dev, src, smp, zxa, zya); } while (0)
+#define ASX_TRY_STATIC(m1, t, maxr, ...) \
+    if (!generic_only() && P.T == (t) && schedule_is(P.st1, m1, { __VA_ARGS__ })) { ASX_LAUNCH(maxr, Sched<m1, __VA_ARGS__>, t); return; }
+    ASX_STATIC_COLS(ASX_TRY_STATIC)
+#undef ASX_TRY_STATIC
     const int mr = max_radix(P.st1);
     if (mr <= 10) ASX_LAUNCH(10); else if (mr <= 12) ASX_LAUNCH(12); else ASX_LAUNCH(16);
 #undef ASX_LAUNCH
@@ -970,12 +1020,15 @@ void asx_launch_rows(const AsxDev &P, const float2 *zxa, const float2 *zya, floa
     size_t lds = asx_lds_bytes_rows(P);
     // diagnostic: a larger request caps the blocks per CU (occupancy sweep, tools/README.md)
     if (const char *e = getenv("ASX_DBG_ROWS_LDS")) lds = std::max(lds, (size_t)atol(e));
-#define ASX_LAUNCH(MAXR) \
-    do { allow_big_lds((const void *)k_rows<MAXR>, lds); \
+#define ASX_LAUNCH(...) \
+    do { allow_big_lds((const void *)k_rows<__VA_ARGS__>, lds); \
          int grid = ntasks; /* one task (pair, k1) per block */ \
-         hipLaunchKernelGGL(k_rows<MAXR>, dim3(grid), dim3(P.threads_rows), lds, s, P.self_dev, zxa, zya, ga, P.row_tasks, P.M1, P.M2, P.M); } while (0)
+         hipLaunchKernelGGL((k_rows<__VA_ARGS__>), dim3(grid), dim3(P.threads_rows), lds, s, P.self_dev, zxa, zya, ga, P.row_tasks, P.M1, P.M2, P.M); } while (0)
     const int mr = max_radix(P.st2);
-    if (mr <= 10) ASX_LAUNCH(10); else if (mr <= 12) ASX_LAUNCH(12); else ASX_LAUNCH(16);
+    // row lengths of the production sample lengths (plan_math.cpp's tuned table): schedule compiled in
+    if (!generic_only() && schedule_is(P.st2, 1200, { 12, 10, 10 })) ASX_LAUNCH(12, Sched<1200, 12, 10, 10>);
+    else if (!generic_only() && schedule_is(P.st2, 480, { 10, 8, 6 })) ASX_LAUNCH(10, Sched<480, 10, 8, 6>);
+    else if (mr <= 10) ASX_LAUNCH(10); else if (mr <= 12) ASX_LAUNCH(12); else ASX_LAUNCH(16);
 #undef ASX_LAUNCH
 }
 
@@ -983,9 +1036,13 @@ void asx_launch_inv_cols(const AsxDev &P, const float2 *ga, const AsxPeakWs &W, 
                          hipStream_t s)
 {
     dim3 grid((P.ntiles + 15) / 16 * 16, npairs);
-#define ASX_LAUNCH(MAXR) \
-    do { allow_big_lds((const void *)k_inv_cols<MAXR>, asx_lds_bytes_cols(P)); \
-         hipLaunchKernelGGL(k_inv_cols<MAXR>, grid, dim3(P.threads_cols), asx_lds_bytes_cols(P), s, P.self_dev, ga, W, r_out); } while (0)
+#define ASX_LAUNCH(...) \
+    do { allow_big_lds((const void *)k_inv_cols<__VA_ARGS__>, asx_lds_bytes_cols(P)); \
+         hipLaunchKernelGGL((k_inv_cols<__VA_ARGS__>), grid, dim3(P.threads_cols), asx_lds_bytes_cols(P), s, P.self_dev, ga, W, r_out); } while (0)
+#define ASX_TRY_STATIC(m1, t, maxr, ...) \
+    if (!generic_only() && P.T == (t) && schedule_is(P.st1, m1, { __VA_ARGS__ })) { ASX_LAUNCH(maxr, Sched<m1, __VA_ARGS__>, t); return; }
+    ASX_STATIC_COLS(ASX_TRY_STATIC)
+#undef ASX_TRY_STATIC
     const int mr = max_radix(P.st1);
     if (mr <= 10) ASX_LAUNCH(10); else if (mr <= 12) ASX_LAUNCH(12); else ASX_LAUNCH(16);
 #undef ASX_LAUNCH
