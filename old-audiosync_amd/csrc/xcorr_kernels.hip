@@ -42,8 +42,31 @@
 
 extern __shared__ __attribute__((aligned(16))) float2 asx_lds[];
 
+// The scalars and table pointers of the plan a kernel uses, copied into registers ONCE at its
+// start.  Read through the plan pointer where they are used, every use after a barrier is another
+// scalar load plus a wait that also drains the LDS queue (the spectral combine of k_rows alone
+// re-read two pointers in each of its five steps).
+struct AsxKP {
+    const float2 *tw1, *tw2, *tw_lo, *tw_hi;
+    const int *pos2_of_k2;
+    uint32_t N, F, M, nout, src_valid, src_period;
+    int M1, M2, T, logT, ntiles;
+    unsigned long long *stamps;
+    int stamp_kernel;
+};
+__device__ __forceinline__ AsxKP asx_kp(const AsxDev &D)
+{
+    AsxKP k;
+    k.tw1 = D.tw1; k.tw2 = D.tw2; k.tw_lo = D.tw_lo; k.tw_hi = D.tw_hi;
+    k.pos2_of_k2 = D.pos2_of_k2;
+    k.N = D.N; k.F = D.F; k.M = D.M; k.nout = D.nout; k.src_valid = D.src_valid; k.src_period = D.src_period;
+    k.M1 = D.M1; k.M2 = D.M2; k.T = D.T; k.logT = D.logT; k.ntiles = D.ntiles;
+    k.stamps = D.stamps; k.stamp_kernel = D.stamp_kernel;
+    return k;
+}
+
 // w_F^p for p < F from the two-level table (one complex multiply, ~1.5e-7 accurate).
-__device__ __forceinline__ float2 tw_F(const AsxDev &P, uint32_t p)
+__device__ __forceinline__ float2 tw_F(const AsxKP &P, uint32_t p)
 {
     const float2 lo = P.tw_lo[p & (ASX_TW_LO - 1u)];
     const float2 hi = P.tw_hi[p >> ASX_TW_LOG];
@@ -90,7 +113,8 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_fwd_cols(const AsxDe
                                                                       float2 *__restrict__ zxa,
                                                                       float2 *__restrict__ zya)
 {
-    const AsxDev &P = *Pp; // plan constants live in device memory: uniform scalar loads
+    const AsxDev &PD = *Pp; // the plan lives in device memory: uniform scalar loads, taken once
+    const AsxKP P = asx_kp(PD);
     const int tile = col_tile_of_block(blockIdx.x);
     if (tile >= P.ntiles) return; // grid.x is rounded up to a multiple of 16
     const bool is_smp = blockIdx.y != 0;
@@ -116,7 +140,7 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_fwd_cols(const AsxDe
     ASX_STAMP_AT(1, stamp_block, 0);
     TwPre pre;
     if constexpr (STATIC) pre = tw_prefetch_first<S1, false, true>(Lc, P.tw1);
-    else pre = tw_prefetch<true>(P.st1, 0, Lc, P.tw1);
+    else pre = tw_prefetch<true>(PD.st1, 0, Lc, P.tw1);
     // all of a thread's tile loads are issued before the first is consumed (ASX_COL_LOADS per
     // round): a rolled loop would pay the HBM latency once per iteration
     // Fast path (block-uniform): full tile, 16-byte aligned rows, no periodic extension, and the
@@ -164,7 +188,7 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_fwd_cols(const AsxDe
     __syncthreads();
     ASX_STAMP_AT(1, stamp_block, 1);
     if constexpr (STATIC) lds_fft_static<S1, false, true>(lds4, Lc, P.tw1, pre);
-    else lds_fft<MAXR, false, true>(lds4, P.st1, Lc, P.tw1, pre);
+    else lds_fft<MAXR, false, true>(lds4, PD.st1, Lc, P.tw1, pre);
     ASX_STAMP_AT(1, stamp_block, 2);
 
     // slot p1 holds frequency k1 = k1_of_pos1[p1] and stays in that slot in HBM; the
@@ -241,7 +265,8 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, ASX_ROWS_MIN_WAVES) void k_row
     // The start of a block is a chain of dependent memory accesses (plan struct -> index table ->
     // rows); M1/M2/M and the task table come as kernel arguments so that ONE 16-byte load
     // (slots and row numbers) separates the block from its row loads.
-    const AsxDev &P = *Pp; // the rest of the plan constants: device memory, uniform scalar loads
+    const AsxDev &PD = *Pp; // the plan lives in device memory: uniform scalar loads, taken once
+    const AsxKP P = asx_kp(PD);
     const int nrows = M1 / 2 + 1;
     float4 *A4 = reinterpret_cast<float4 *>(asx_lds), *B4 = A4 + M2;
     float2 *C2 = asx_lds; // the same storage seen as complex values: slot e = C2[2e] (member 0), C2[2e+1]
@@ -280,7 +305,7 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, ASX_ROWS_MIN_WAVES) void k_row
         }
         TwPre pre_f;
         if constexpr (STATIC) pre_f = tw_prefetch_first<S2, false, false>(Lf, P.tw2);
-        else pre_f = tw_prefetch<false>(P.st2, 0, Lf, P.tw2);
+        else pre_f = tw_prefetch<false>(PD.st2, 0, Lf, P.tw2);
 
         // Four-step twiddle of row k1: w_M^(k1*j2) with j2 = t + blockDim*i factors into
         // w_M^(k1*t) (one two-level lookup per thread) times w_M^(k1*blockDim*i) (a handful per block).
@@ -311,7 +336,7 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, ASX_ROWS_MIN_WAVES) void k_row
         __syncthreads();
         ASX_STAMP(1);
         if constexpr (STATIC) lds_fft_static<S2, false, false>(A4, Lf, P.tw2, pre_f);
-        else lds_fft<MAXR, false, false>(A4, P.st2, Lf, P.tw2, pre_f);
+        else lds_fft<MAXR, false, false>(A4, PD.st2, Lf, P.tw2, pre_f);
         ASX_STAMP(2);
 
         // ---- spectral combine.  Every thread first computes its G values into registers (it
@@ -357,7 +382,7 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, ASX_ROWS_MIN_WAVES) void k_row
         });
         TwPre pre_i;
         if constexpr (STATIC) pre_i = tw_prefetch_first<S2, true, false>(Li, P.tw2);
-        else pre_i = tw_prefetch<false>(P.st2, P.st2.nstages - 1, Li, P.tw2);
+        else pre_i = tw_prefetch<false>(PD.st2, PD.st2.nstages - 1, Li, P.tw2);
         __syncthreads();
         static_for<0, ASX_ROW_STEPS>([&](auto I) __attribute__((always_inline)) {
             constexpr int i = decltype(I)::value;
@@ -376,7 +401,7 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, ASX_ROWS_MIN_WAVES) void k_row
         ASX_STAMP(3);
         // inverse row transforms of the G pair, digit-reversed in -> natural j2 out
         if constexpr (STATIC) lds_fft_static<S2, true, false>(A4, Li, P.tw2, pre_i);
-        else lds_fft<MAXR, true, false>(A4, P.st2, Li, P.tw2, pre_i);
+        else lds_fft<MAXR, true, false>(A4, PD.st2, Li, P.tw2, pre_i);
         ASX_STAMP(4);
 
         // inverse four-step twiddle conj(w_M^(k1*j2)) / conj(w_M^(m1*j2)), one per member
@@ -483,7 +508,8 @@ template <int MAXR, class S1 = void, int TC = 0>
 __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_inv_cols(const AsxDev *__restrict__ Pp, const float2 *__restrict__ ga,
                                                                    AsxPeakWs W, float *__restrict__ r_out)
 {
-    const AsxDev &P = *Pp; // plan constants live in device memory: uniform scalar loads
+    const AsxDev &PD = *Pp; // the plan lives in device memory: uniform scalar loads, taken once
+    const AsxKP P = asx_kp(PD);
     __shared__ asx_peak_t red[ASX_FFT_THREADS_MAX / 64];
     __shared__ asx_peak_t tile_best;
     __shared__ uint32_t ncand;
@@ -507,7 +533,7 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_inv_cols(const AsxDe
     ASX_STAMP_AT(2, stamp_block, 0);
     TwPre pre;
     if constexpr (STATIC) pre = tw_prefetch_first<S1, true, true>(Lc, P.tw1);
-    else pre = tw_prefetch<true>(P.st1, P.st1.nstages - 1, Lc, P.tw1);
+    else pre = tw_prefetch<true>(PD.st1, PD.st1.nstages - 1, Lc, P.tw1);
     for (int e0 = threadIdx.x; e0 < nelem4; e0 += ASX_COL_LOADS * blockDim.x) {
         float4 v[ASX_COL_LOADS];
         static_for<0, ASX_COL_LOADS>([&](auto I) __attribute__((always_inline)) {
@@ -537,7 +563,7 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_inv_cols(const AsxDe
     __syncthreads();
     ASX_STAMP_AT(2, stamp_block, 1);
     if constexpr (STATIC) lds_fft_static<S1, true, true>(lds4, Lc, P.tw1, pre);
-    else lds_fft<MAXR, true, true>(lds4, P.st1, Lc, P.tw1, pre);
+    else lds_fft<MAXR, true, true>(lds4, PD.st1, Lc, P.tw1, pre);
     ASX_STAMP_AT(2, stamp_block, 2);
 
     // Peak search.  A thread meets its lags in increasing order, so a strict '>' keeps the
@@ -681,7 +707,8 @@ __device__ __forceinline__ AsxSeg make_seg(uint32_t peak, uint32_t N)
 
 __global__ __launch_bounds__(ASX_THREADS) void k_finalize(const AsxDev *__restrict__ Pp, AsxPeakWs W, AsxSeg *__restrict__ seg)
 {
-    const AsxDev &P = *Pp; // plan constants live in device memory: uniform scalar loads
+    const AsxDev &PD = *Pp; // the plan lives in device memory: uniform scalar loads, taken once
+    const AsxKP P = asx_kp(PD);
     __shared__ asx_peak_t red[ASX_THREADS / 64];
     __shared__ asx_peak_t pair_best;
     __shared__ uint32_t nsel, overflow;
@@ -730,7 +757,8 @@ template <typename TIn>
 __global__ __launch_bounds__(ASX_THREADS) void k_refine_dots(const AsxDev *__restrict__ Pp, const TIn *__restrict__ src,
                                                               const TIn *__restrict__ smp, AsxPeakWs W)
 {
-    const AsxDev &P = *Pp; // plan constants live in device memory: uniform scalar loads
+    const AsxDev &PD = *Pp; // the plan lives in device memory: uniform scalar loads, taken once
+    const AsxKP P = asx_kp(PD);
     __shared__ double red[ASX_THREADS / 64];
     const size_t pair = blockIdx.y;
     if (blockIdx.x >= W.refine_n[pair]) return;
@@ -758,7 +786,8 @@ __global__ __launch_bounds__(ASX_THREADS) void k_refine_dots(const AsxDev *__res
 // grid (npairs), one thread decides: the reference's max_abs_index rule on the exact values
 __global__ __launch_bounds__(64) void k_refine_pick(const AsxDev *__restrict__ Pp, AsxPeakWs W, AsxSeg *__restrict__ seg)
 {
-    const AsxDev &P = *Pp; // plan constants live in device memory: uniform scalar loads
+    const AsxDev &PD = *Pp; // the plan lives in device memory: uniform scalar loads, taken once
+    const AsxKP P = asx_kp(PD);
     const size_t pair = blockIdx.x;
     const uint32_t n = W.refine_n[pair];
     if (n < 2u || threadIdx.x != 0) return;
