@@ -516,3 +516,54 @@ def test_broad_peak_of_a_smooth_signal_is_resolved_exactly(mod):
         assert margin < 1.0 + 1e-5            # it IS a near-tie for float32
         assert (ret, lag) == (o_ret, o_lag)      # (circular wrap terms may move the peak off d; parity is the point)
         assert abs(coef - o_coef) < COEF_TOL
+
+
+# ---- generic (run-time schedule) kernels against the compiled-in schedules -----------------------
+
+_GENERIC_PROBE = r"""
+import json, sys
+sys.path.insert(0, %(root)r)
+import numpy as np
+import __graft_entry__ as g
+import oracle
+asx = g.load()
+out = {}
+for n in (144000, 480000):
+    pairs = [oracle.synth_pair(23, p, n, 0) for p in range(3)]
+    src = np.stack([p[0] for p in pairs]); smp = np.stack([p[1] for p in pairs])
+    with asx.Plan(n, 3, 0) as plan:
+        lag, coef, ret = plan.xcorr_batch_f32(src, smp)
+    out[str(n)] = {"lag": [int(x) for x in lag], "coef": [float(x) for x in coef], "ret": [int(x) for x in ret]}
+print("RESULT " + json.dumps(out))
+"""
+
+
+def test_generic_kernels_agree_with_compiled_in_schedules(mod):
+    """The launchers pick kernels with a compile-time schedule for the production lengths
+    (xcorr_kernels.hip, ASX_STATIC_COLS / asx_launch_rows); ASX_GENERIC=1 (read once per process)
+    forces the run-time-schedule kernels every other length uses.  Same inputs, same answers,
+    and both equal to the oracle."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    got = {}
+    for label, env_extra in (("static", {}), ("generic", {"ASX_GENERIC": "1"})):
+        env = dict(os.environ)
+        env.pop("ASX_GENERIC", None)
+        env.update(env_extra)
+        p = subprocess.run([sys.executable, "-c", _GENERIC_PROBE % {"root": root}], env=env, capture_output=True,
+                           text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        line = [l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1]
+        got[label] = json.loads(line[len("RESULT "):])
+    assert got["static"].keys() == got["generic"].keys()
+    for n in got["static"]:
+        assert got["static"][n]["lag"] == got["generic"][n]["lag"]
+        assert got["static"][n]["ret"] == got["generic"][n]["ret"]
+        assert got["static"][n]["coef"] == got["generic"][n]["coef"]   # same lag, same float64 reduction tree
+        for p in range(3):
+            s, t, _ = oracle.synth_pair(23, p, int(n), 0)
+            o_ret, o_lag, o_coef = oracle.cross_correlation(s, t)
+            assert got["static"][n]["lag"][p] == o_lag and got["static"][n]["ret"][p] == o_ret
+            assert abs(got["static"][n]["coef"][p] - o_coef) < COEF_TOL
