@@ -309,6 +309,7 @@ struct LdsLayout {
     int ngroups, log_ngroups;  // transform pairs in the tile
     int elem_stride;           // in float4 slots
     int group_stride;
+    int nthreads;              // block size (a literal in the kernels with a compile-time schedule)
 };
 
 // Twiddle prefetch: the two table reads (W^1, W^4) a thread needs for its FIRST work item of a
@@ -415,7 +416,7 @@ __device__ __forceinline__ void lds_stage(float4 *lds, const StageK K, const Lds
     const float inv_q = K.inv_q, inv_nbf = K.inv_nbf;
     const int total = L.ngroups * nbf;
     const int step = q * L.elem_stride;
-    for (int w = threadIdx.x; w < total; w += blockDim.x) {
+    for (int w = threadIdx.x; w < total; w += L.nthreads) {
         int g, bf;
         if (GFAST) {
             g = w & (L.ngroups - 1);

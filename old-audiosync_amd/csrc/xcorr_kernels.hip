@@ -90,13 +90,14 @@ __device__ __forceinline__ int col_tile_of_block(int b)
     return (b & ~15) + 2 * (b & 7) + ((b >> 3) & 1);
 }
 
-__device__ __forceinline__ LdsLayout col_layout(int T, int logT)
+__device__ __forceinline__ LdsLayout col_layout(int T, int logT, int nthreads)
 {
     LdsLayout L;
     L.ngroups = T >> 1;
     L.log_ngroups = logT - 1;
     L.elem_stride = T >> 1;
     L.group_stride = 1;
+    L.nthreads = nthreads;
     return L;
 }
 constexpr int asx_ilog2(int v) { return v <= 1 ? 0 : 1 + asx_ilog2(v >> 1); }
@@ -104,9 +105,10 @@ constexpr int asx_ilog2(int v) { return v <= 1 ? 0 : 1 + asx_ilog2(v >> 1); }
 // k_fwd_cols: grid (ntiles, 2, npairs).  blockIdx.y: 0 = source, 1 = sample.
 // Packs real samples as complex (z[j] = x[2j] + i x[2j+1]); zero padding and the periodic
 // extension of the source (embedded lengths) happen in the loads, never in HBM.
-// S1 = void, TC = 0: column schedule and tile width from the plan at run time (any length);
-// S1 = Sched<M1, radices...>, TC = tile width: compiled in (production lengths, see the launchers).
-template <int MAXR, class S1 = void, int TC = 0>
+// S1 = void: column schedule, tile width and block size from the plan at run time (any length);
+// S1 = Sched<M1, radices...>, TC = tile width, NT = block size: compiled in (production lengths,
+// see the launchers).
+template <int MAXR, class S1 = void, int TC = 0, int NT = 0>
 __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_fwd_cols(const AsxDev *__restrict__ Pp,
                                                                       const float *__restrict__ src,
                                                                       const float *__restrict__ smp,
@@ -121,7 +123,8 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_fwd_cols(const AsxDe
     const size_t pair = blockIdx.z;
     constexpr bool STATIC = !std::is_void<S1>::value;
     int T = P.T, logT = P.logT, M1 = P.M1;
-    if constexpr (STATIC) { T = TC; logT = asx_ilog2(TC); M1 = S1::n; }
+    int nthreads = blockDim.x;
+    if constexpr (STATIC) { T = TC; logT = asx_ilog2(TC); M1 = S1::n; nthreads = NT; }
     const int logH = logT - 1, H = T >> 1, M2 = P.M2;
     const int c0 = tile * T;
 
@@ -134,7 +137,7 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_fwd_cols(const AsxDe
     float4 *lds4 = reinterpret_cast<float4 *>(asx_lds);
 
     const int nelem4 = M1 << logH;
-    const LdsLayout Lc = col_layout(T, logT);
+    const LdsLayout Lc = col_layout(T, logT, nthreads);
     const size_t stamp_block = (pair * 2 + blockIdx.y) * P.ntiles + tile;
     (void)stamp_block;
     ASX_STAMP_AT(1, stamp_block, 0);
@@ -148,11 +151,11 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_fwd_cols(const AsxDe
     const uint32_t row_reals = 2u * (uint32_t)M2;                 // real samples per matrix row
     const bool fast = vec_in && (c0 + T <= M2) && (valid <= period) && (valid % row_reals == 0u);
     const int data_rows = fast ? (int)(valid / row_reals) : 0;     // rows below this are all data
-    for (int e0 = threadIdx.x; e0 < nelem4; e0 += ASX_COL_LOADS * blockDim.x) {
+    for (int e0 = threadIdx.x; e0 < nelem4; e0 += ASX_COL_LOADS * nthreads) {
         float4 v[ASX_COL_LOADS];
         if (fast) {
             static_for<0, ASX_COL_LOADS>([&](auto I) __attribute__((always_inline)) {
-                const int e = e0 + decltype(I)::value * blockDim.x;
+                const int e = e0 + decltype(I)::value * nthreads;
                 const int cg = e & (H - 1), j1 = e >> logH;
                 v[I] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (j1 < data_rows) // also false for e >= nelem4 (j1 >= M1 >= data_rows)
@@ -160,7 +163,7 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_fwd_cols(const AsxDe
             });
         } else {
         static_for<0, ASX_COL_LOADS>([&](auto I) __attribute__((always_inline)) {
-            const int e = e0 + decltype(I)::value * blockDim.x;
+            const int e = e0 + decltype(I)::value * nthreads;
             const int cg = e & (H - 1), j1 = e >> logH;
             const int j2 = c0 + 2 * cg;
             v[I] = make_float4(0.f, 0.f, 0.f, 0.f); // (re0, im0, re1, im1) as it lies in memory
@@ -181,7 +184,7 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_fwd_cols(const AsxDe
         });
         }
         static_for<0, ASX_COL_LOADS>([&](auto I) __attribute__((always_inline)) {
-            const int e = e0 + decltype(I)::value * blockDim.x;
+            const int e = e0 + decltype(I)::value * nthreads;
             if (e < nelem4) lds4[e] = v[I];
         });
     }
@@ -194,7 +197,7 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_fwd_cols(const AsxDe
     // slot p1 holds frequency k1 = k1_of_pos1[p1] and stays in that slot in HBM; the
     // four-step twiddle w_M^(k1*j2) is applied by k_rows, where k1 is block-uniform.
     const bool full = even && (c0 + T <= M2);
-    for (int e = threadIdx.x; e < nelem4; e += blockDim.x) {
+    for (int e = threadIdx.x; e < nelem4; e += nthreads) {
         const int cg = e & (H - 1), p1 = e >> logH;
         const int j2 = c0 + 2 * cg;
         if (full) {
@@ -251,7 +254,7 @@ struct RowRegs {
 
 // S2 = void: schedule of the row transforms read from the plan at run time (any length);
 // S2 = Sched<M2, radices...>: compiled in (the production lengths, see asx_launch_rows).
-template <int MAXR, class S2 = void>
+template <int MAXR, class S2 = void, int NT = 0>
 __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, ASX_ROWS_MIN_WAVES) void k_rows(const AsxDev *__restrict__ Pp,
                                                                   const float2 *__restrict__ zxa,
                                                                   const float2 *__restrict__ zya,
@@ -260,8 +263,8 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, ASX_ROWS_MIN_WAVES) void k_row
                                                                   int M1, int M2_arg, uint32_t M)
 {
     constexpr bool STATIC = !std::is_void<S2>::value;
-    int M2 = M2_arg;
-    if constexpr (STATIC) M2 = S2::n;
+    int M2 = M2_arg, nthreads = blockDim.x;
+    if constexpr (STATIC) { M2 = S2::n; nthreads = NT; }
     // The start of a block is a chain of dependent memory accesses (plan struct -> index table ->
     // rows); M1/M2/M and the task table come as kernel arguments so that ONE 16-byte load
     // (slots and row numbers) separates the block from its row loads.
@@ -282,16 +285,16 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, ASX_ROWS_MIN_WAVES) void k_row
         ASX_STAMP(0);
         LdsLayout Lf;
         Lf.ngroups = self ? 1 : 2; Lf.log_ngroups = 0;
-        Lf.elem_stride = 1; Lf.group_stride = M2;
+        Lf.elem_stride = 1; Lf.group_stride = M2; Lf.nthreads = nthreads;
         LdsLayout Li;
         Li.ngroups = 1; Li.log_ngroups = 0;
-        Li.elem_stride = 1; Li.group_stride = 0;
+        Li.elem_stride = 1; Li.group_stride = 0; Li.nthreads = nthreads;
         // every row load of the thread is issued first; the twiddle lookups below overlap them
         RowRegs L;
         {
             const float2 *gx = zxa + (size_t)pair * M, *gy = zya + (size_t)pair * M;
             static_for<0, ASX_ROW_STEPS>([&](auto I) __attribute__((always_inline)) {
-                const int j2 = threadIdx.x + decltype(I)::value * blockDim.x;
+                const int j2 = threadIdx.x + decltype(I)::value * nthreads;
                 L.xa[I] = L.ya[I] = L.xb[I] = L.yb[I] = make_float2(0.f, 0.f);
                 if (j2 < M2) {
                     L.xa[I] = gx[(size_t)pa * M2 + j2];
@@ -309,12 +312,12 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, ASX_ROWS_MIN_WAVES) void k_row
 
         // Four-step twiddle of row k1: w_M^(k1*j2) with j2 = t + blockDim*i factors into
         // w_M^(k1*t) (one two-level lookup per thread) times w_M^(k1*blockDim*i) (a handful per block).
-        const int nsteps = (M2 + (int)blockDim.x - 1) / (int)blockDim.x; // <= ASX_ROW_STEPS (launcher)
+        const int nsteps = (M2 + nthreads - 1) / nthreads; // <= ASX_ROW_STEPS (launcher)
         if ((int)threadIdx.x < 2 * nsteps) {
             const int which = (int)threadIdx.x >= nsteps;
             const int i = threadIdx.x - which * nsteps;
             const uint32_t row = which ? (uint32_t)m1 : (uint32_t)k1;
-            tw_step[which][i] = tw_F(P, 2u * row * (uint32_t)(i * (int)blockDim.x));
+            tw_step[which][i] = tw_F(P, 2u * row * (uint32_t)(i * nthreads));
         }
         const uint32_t tcol = threadIdx.x < (unsigned)M2 ? threadIdx.x : 0u;
         {
@@ -323,7 +326,7 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, ASX_ROWS_MIN_WAVES) void k_row
             __syncthreads();
             static_for<0, ASX_ROW_STEPS>([&](auto I) __attribute__((always_inline)) {
                 constexpr int i = decltype(I)::value;
-                const int j2 = threadIdx.x + i * blockDim.x;
+                const int j2 = threadIdx.x + i * nthreads;
                 if (j2 < M2) {
                     lds_put(A4 + j2, mulw(Cx2{ v2f{ L.xa[I].x, L.ya[I].x }, v2f{ L.xa[I].y, L.ya[I].y } },
                                           cmul(twa, tw_step[0][i])));
@@ -347,7 +350,7 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, ASX_ROWS_MIN_WAVES) void k_row
         int sa[ASX_ROW_STEPS], sb[ASX_ROW_STEPS]; // -1: nothing to write
         static_for<0, ASX_ROW_STEPS>([&](auto I) __attribute__((always_inline)) {
             constexpr int i = decltype(I)::value;
-            const int k2 = threadIdx.x + i * blockDim.x;
+            const int k2 = threadIdx.x + i * nthreads;
             sa[i] = -1; sb[i] = -1;
             gk[i] = make_float2(0.f, 0.f); gm[i] = make_float2(0.f, 0.f);
             if (!self) {
@@ -408,7 +411,7 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, ASX_ROWS_MIN_WAVES) void k_row
         float2 *go = ga + (size_t)pair * M;
         const float2 twa = tw_F(P, 2u * (uint32_t)k1 * tcol); // looked up again: cheaper than 4 live VGPRs
         const float2 twb = tw_F(P, 2u * (uint32_t)m1 * tcol);
-        for (int j2 = threadIdx.x, i = 0; j2 < M2; j2 += blockDim.x, i++) {
+        for (int j2 = threadIdx.x, i = 0; j2 < M2; j2 += nthreads, i++) {
             const float2 wa = cmul(twa, tw_step[0][i]), wb = cmul(twb, tw_step[1][i]);
             const Cx2 g = mul2c(lds_get(A4 + j2), Cx2{ v2f{ wa.x, wb.x }, v2f{ wa.y, wb.y } });
             go[(size_t)pa * M2 + j2] = make_float2(g.re.x, g.im.x);
@@ -504,7 +507,7 @@ __device__ __forceinline__ float near_max_threshold(float kmax)
     return kmax > 0.f ? kmax * (1.0f - ASX_REFINE_EPS) : kmax;
 }
 
-template <int MAXR, class S1 = void, int TC = 0>
+template <int MAXR, class S1 = void, int TC = 0, int NT = 0>
 __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_inv_cols(const AsxDev *__restrict__ Pp, const float2 *__restrict__ ga,
                                                                    AsxPeakWs W, float *__restrict__ r_out)
 {
@@ -519,7 +522,8 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_inv_cols(const AsxDe
     const size_t pair = blockIdx.y;
     constexpr bool STATIC = !std::is_void<S1>::value;
     int T = P.T, logT = P.logT, M1 = P.M1;
-    if constexpr (STATIC) { T = TC; logT = asx_ilog2(TC); M1 = S1::n; }
+    int nthreads = blockDim.x;
+    if constexpr (STATIC) { T = TC; logT = asx_ilog2(TC); M1 = S1::n; nthreads = NT; }
     const int logH = logT - 1, H = T >> 1, M2 = P.M2;
     const int c0 = tile * T;
     const float2 *in = ga + pair * (size_t)P.M;
@@ -527,17 +531,17 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_inv_cols(const AsxDe
     float4 *lds4 = reinterpret_cast<float4 *>(asx_lds);
 
     const int nelem4 = M1 << logH;
-    const LdsLayout Lc = col_layout(T, logT);
+    const LdsLayout Lc = col_layout(T, logT, nthreads);
     const size_t stamp_block = pair * P.ntiles + tile;
     (void)stamp_block;
     ASX_STAMP_AT(2, stamp_block, 0);
     TwPre pre;
     if constexpr (STATIC) pre = tw_prefetch_first<S1, true, true>(Lc, P.tw1);
     else pre = tw_prefetch<true>(PD.st1, PD.st1.nstages - 1, Lc, P.tw1);
-    for (int e0 = threadIdx.x; e0 < nelem4; e0 += ASX_COL_LOADS * blockDim.x) {
+    for (int e0 = threadIdx.x; e0 < nelem4; e0 += ASX_COL_LOADS * nthreads) {
         float4 v[ASX_COL_LOADS];
         static_for<0, ASX_COL_LOADS>([&](auto I) __attribute__((always_inline)) {
-            const int e = e0 + decltype(I)::value * blockDim.x;
+            const int e = e0 + decltype(I)::value * nthreads;
             const int cg = e & (H - 1), p1 = e >> logH;
             const int j2 = c0 + 2 * cg;
             v[I] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -555,7 +559,7 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_inv_cols(const AsxDe
             }
         });
         static_for<0, ASX_COL_LOADS>([&](auto I) __attribute__((always_inline)) {
-            const int e = e0 + decltype(I)::value * blockDim.x;
+            const int e = e0 + decltype(I)::value * nthreads;
             if (e < nelem4) lds4[e] = v[I];
         });
     }
@@ -594,7 +598,7 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_inv_cols(const AsxDe
         // pass 1: per thread the largest and second largest slot maximum
         float best_m = -INFINITY, second_m = -INFINITY;
         int best_e = threadIdx.x;
-        for (int e = threadIdx.x; e < nelem4; e += blockDim.x) {
+        for (int e = threadIdx.x; e < nelem4; e += nthreads) {
             const float4 g = lds4[e];
             const float m = fmaxf(fmaxf(fabsf(g.x), fabsf(g.y)), fmaxf(fabsf(g.z), fabsf(g.w))); // NaNs drop out
             if (m > best_m) { second_m = best_m; best_m = m; best_e = e; }
@@ -623,7 +627,7 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_inv_cols(const AsxDe
         __syncthreads();
         // every thread folds the wave entries itself: no second barrier to broadcast the result
         asx_peak_t tb = red[0];
-        for (int w = 1; w < (int)((blockDim.x + 63) >> 6); w++) tb = peak_max(tb, red[w]);
+        for (int w = 1; w < (int)((nthreads + 63) >> 6); w++) tb = peak_max(tb, red[w]);
         if (threadIdx.x == 0) tile_best = tb;
         // second look at the tile (still in LDS): lags as large as the tile maximum within float32
         // accuracy.  Almost every thread is below the threshold; the one that holds the maximum
@@ -631,7 +635,7 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_inv_cols(const AsxDe
         const float thr = near_max_threshold(peak_key(tb));
         if (best_m >= thr) {
             if (second_m >= thr) {
-                for (int e = threadIdx.x; e < nelem4; e += blockDim.x) {
+                for (int e = threadIdx.x; e < nelem4; e += nthreads) {
                     const float4 g = lds4[e];
                     const float m = fmaxf(fmaxf(fabsf(g.x), fabsf(g.y)), fmaxf(fabsf(g.z), fabsf(g.w)));
                     if (m >= thr) examine_slot(e, g, thr);
@@ -644,7 +648,7 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_inv_cols(const AsxDe
         asx_peak_t best = 0;
         float best_key = -INFINITY;
         uint32_t best_idx = 0xFFFFFFFFu;
-        for (int e = threadIdx.x; e < nelem4; e += blockDim.x) {
+        for (int e = threadIdx.x; e < nelem4; e += nthreads) {
             const int cg = e & (H - 1), j1 = e >> logH;
             const int j2 = c0 + 2 * cg;
             if (j2 < M2) {
@@ -669,7 +673,7 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_inv_cols(const AsxDe
         // second look at the tile (still in LDS): lags as large as the tile maximum within
         // float32 accuracy.  A lag near the GLOBAL maximum is necessarily near its tile's maximum.
         const float thr = near_max_threshold(peak_key(tile_best));
-        for (int e = threadIdx.x; e < nelem4; e += blockDim.x) examine_slot(e, lds4[e], thr);
+        for (int e = threadIdx.x; e < nelem4; e += nthreads) examine_slot(e, lds4[e], thr);
     }
     __syncthreads();
     const size_t t = pair * (size_t)P.ntiles + tile;
@@ -1022,9 +1026,10 @@ static bool generic_only()
     return g;
 }
 // Column schedules of the production sample lengths (plan_math.cpp's tuned table), compiled in:
-//   X(M1, tile width, MAXR for the launch bounds, radices...)
+//   X(M1, tile width, block size, MAXR for the launch bounds, radices...)
 #define ASX_STATIC_COLS(X) \
-    X(1200, 8, 12, 12, 10, 10) X(800, 8, 10, 10, 10, 8) X(600, 16, 10, 10, 10, 6) X(400, 16, 10, 10, 8, 5) X(300, 16, 10, 10, 6, 5)
+    X(1200, 8, 512, 12, 12, 10, 10) X(800, 8, 320, 10, 10, 10, 8) X(600, 16, 512, 10, 10, 10, 6) \
+    X(400, 16, 320, 10, 10, 8, 5) X(300, 16, 256, 10, 10, 6, 5)
 
 void asx_launch_fwd_cols(const AsxDev &P, const float *src, const float *smp, float2 *zxa,
                          float2 *zya, int npairs, hipStream_t s)
@@ -1033,8 +1038,8 @@ void asx_launch_fwd_cols(const AsxDev &P, const float *src, const float *smp, fl
 #define ASX_LAUNCH(...) \
     do { allow_big_lds((const void *)k_fwd_cols<__VA_ARGS__>, asx_lds_bytes_cols(P)); \
          hipLaunchKernelGGL((k_fwd_cols<__VA_ARGS__>), grid, dim3(P.threads_cols), asx_lds_bytes_cols(P), s, P.self_dev, src, smp, zxa, zya); } while (0)
-#define ASX_TRY_STATIC(m1, t, maxr, ...) \
-    if (!generic_only() && P.T == (t) && schedule_is(P.st1, m1, { __VA_ARGS__ })) { ASX_LAUNCH(maxr, Sched<m1, __VA_ARGS__>, t); return; }
+#define ASX_TRY_STATIC(m1, t, nt, maxr, ...) \
+    if (!generic_only() && P.T == (t) && P.threads_cols == (nt) && schedule_is(P.st1, m1, { __VA_ARGS__ })) { ASX_LAUNCH(maxr, Sched<m1, __VA_ARGS__>, t, nt); return; }
     ASX_STATIC_COLS(ASX_TRY_STATIC)
 #undef ASX_TRY_STATIC
     const int mr = max_radix(P.st1);
@@ -1055,8 +1060,8 @@ void asx_launch_rows(const AsxDev &P, const float2 *zxa, const float2 *zya, floa
          hipLaunchKernelGGL((k_rows<__VA_ARGS__>), dim3(grid), dim3(P.threads_rows), lds, s, P.self_dev, zxa, zya, ga, P.row_tasks, P.M1, P.M2, P.M); } while (0)
     const int mr = max_radix(P.st2);
     // row lengths of the production sample lengths (plan_math.cpp's tuned table): schedule compiled in
-    if (!generic_only() && schedule_is(P.st2, 1200, { 12, 10, 10 })) ASX_LAUNCH(12, Sched<1200, 12, 10, 10>);
-    else if (!generic_only() && schedule_is(P.st2, 480, { 10, 8, 6 })) ASX_LAUNCH(10, Sched<480, 10, 8, 6>);
+    if (!generic_only() && P.threads_rows == 256 && schedule_is(P.st2, 1200, { 12, 10, 10 })) ASX_LAUNCH(12, Sched<1200, 12, 10, 10>, 256);
+    else if (!generic_only() && P.threads_rows == 128 && schedule_is(P.st2, 480, { 10, 8, 6 })) ASX_LAUNCH(10, Sched<480, 10, 8, 6>, 128);
     else if (mr <= 10) ASX_LAUNCH(10); else if (mr <= 12) ASX_LAUNCH(12); else ASX_LAUNCH(16);
 #undef ASX_LAUNCH
 }
@@ -1068,8 +1073,8 @@ void asx_launch_inv_cols(const AsxDev &P, const float2 *ga, const AsxPeakWs &W, 
 #define ASX_LAUNCH(...) \
     do { allow_big_lds((const void *)k_inv_cols<__VA_ARGS__>, asx_lds_bytes_cols(P)); \
          hipLaunchKernelGGL((k_inv_cols<__VA_ARGS__>), grid, dim3(P.threads_cols), asx_lds_bytes_cols(P), s, P.self_dev, ga, W, r_out); } while (0)
-#define ASX_TRY_STATIC(m1, t, maxr, ...) \
-    if (!generic_only() && P.T == (t) && schedule_is(P.st1, m1, { __VA_ARGS__ })) { ASX_LAUNCH(maxr, Sched<m1, __VA_ARGS__>, t); return; }
+#define ASX_TRY_STATIC(m1, t, nt, maxr, ...) \
+    if (!generic_only() && P.T == (t) && P.threads_cols == (nt) && schedule_is(P.st1, m1, { __VA_ARGS__ })) { ASX_LAUNCH(maxr, Sched<m1, __VA_ARGS__>, t, nt); return; }
     ASX_STATIC_COLS(ASX_TRY_STATIC)
 #undef ASX_TRY_STATIC
     const int mr = max_radix(P.st1);
