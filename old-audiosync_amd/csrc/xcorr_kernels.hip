@@ -348,17 +348,38 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, ASX_ROWS_MIN_WAVES) void k_row
         const float2 wA = tw_F(P, 2u * (uint32_t)k1); // w_M^k1, block-uniform; w_M^(k1 + M1*k2) = wA * w_M2^k2
         float2 gk[ASX_ROW_STEPS], gm[ASX_ROW_STEPS];
         int sa[ASX_ROW_STEPS], sb[ASX_ROW_STEPS]; // -1: nothing to write
+        if (!self) {
+            // The common case, written as three sweeps over the thread's bins so that the table
+            // reads of all of them are in flight together, then the LDS reads, then the arithmetic
+            // (step by step, each bin would wait for its own table read and its own LDS read).
+            float2 w2[ASX_ROW_STEPS];
+            static_for<0, ASX_ROW_STEPS>([&](auto I) __attribute__((always_inline)) {
+                constexpr int i = decltype(I)::value;
+                const int k2 = threadIdx.x + i * nthreads;
+                const int kc = k2 < M2 ? k2 : 0; // clamped: the loads are unconditional
+                sa[i] = P.pos2_of_k2[kc];
+                sb[i] = P.pos2_of_k2[M2 - 1 - kc];
+                w2[i] = P.tw2[kc];
+            });
+            Cx2 za[ASX_ROW_STEPS], zb[ASX_ROW_STEPS];
+            static_for<0, ASX_ROW_STEPS>([&](auto I) __attribute__((always_inline)) {
+                constexpr int i = decltype(I)::value;
+                za[i] = lds_get(A4 + sa[i]);
+                zb[i] = lds_get(B4 + sb[i]);
+            });
+            static_for<0, ASX_ROW_STEPS>([&](auto I) __attribute__((always_inline)) {
+                constexpr int i = decltype(I)::value;
+                const int k2 = threadIdx.x + i * nthreads;
+                combine_pair(za[i], zb[i], cmul(wA, w2[i]), gk[i], gm[i]);
+                if (k2 >= M2) sa[i] = -1;
+            });
+        } else {
         static_for<0, ASX_ROW_STEPS>([&](auto I) __attribute__((always_inline)) {
             constexpr int i = decltype(I)::value;
             const int k2 = threadIdx.x + i * nthreads;
             sa[i] = -1; sb[i] = -1;
             gk[i] = make_float2(0.f, 0.f); gm[i] = make_float2(0.f, 0.f);
-            if (!self) {
-                if (k2 < M2) {
-                    sa[i] = P.pos2_of_k2[k2]; sb[i] = P.pos2_of_k2[M2 - 1 - k2];
-                    combine_pair(lds_get(A4 + sa[i]), lds_get(B4 + sb[i]), cmul(wA, P.tw2[k2]), gk[i], gm[i]);
-                }
-            } else if (k1 == 0) {
+            if (k1 == 0) {
                 if (k2 == 0) {
                     // DC and Nyquist bins are real: X[0] = Re Z0 + Im Z0, X[M] = Re Z0 - Im Z0
                     const Cx2 z = lds_get(A4);
@@ -383,6 +404,7 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, ASX_ROWS_MIN_WAVES) void k_row
                 }
             }
         });
+        }
         TwPre pre_i;
         if constexpr (STATIC) pre_i = tw_prefetch_first<S2, true, false>(Li, P.tw2);
         else pre_i = tw_prefetch<false>(PD.st2, PD.st2.nstages - 1, Li, P.tw2);
