@@ -320,9 +320,9 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, ASX_ROWS_MIN_WAVES) void k_row
             tw_step[which][i] = tw_F(P, 2u * row * (uint32_t)(i * nthreads));
         }
         const uint32_t tcol = threadIdx.x < (unsigned)M2 ? threadIdx.x : 0u;
+        const float2 twa = tw_F(P, 2u * (uint32_t)k1 * tcol);
+        const float2 twb = tw_F(P, 2u * (uint32_t)m1 * tcol);
         {
-            const float2 twa = tw_F(P, 2u * (uint32_t)k1 * tcol);
-            const float2 twb = tw_F(P, 2u * (uint32_t)m1 * tcol);
             __syncthreads();
             static_for<0, ASX_ROW_STEPS>([&](auto I) __attribute__((always_inline)) {
                 constexpr int i = decltype(I)::value;
@@ -429,16 +429,26 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, ASX_ROWS_MIN_WAVES) void k_row
         else lds_fft<MAXR, true, false>(A4, PD.st2, Li, P.tw2, pre_i);
         ASX_STAMP(4);
 
-        // inverse four-step twiddle conj(w_M^(k1*j2)) / conj(w_M^(m1*j2)), one per member
+        // inverse four-step twiddle conj(w_M^(k1*j2)) / conj(w_M^(m1*j2)), one per member; unrolled so
+        // that the LDS reads of all steps are in flight together (a rolled loop pays the LDS latency
+        // once per step).  twa / twb ride in registers from the load phase.
         float2 *go = ga + (size_t)pair * M;
-        const float2 twa = tw_F(P, 2u * (uint32_t)k1 * tcol); // looked up again: cheaper than 4 live VGPRs
-        const float2 twb = tw_F(P, 2u * (uint32_t)m1 * tcol);
-        for (int j2 = threadIdx.x, i = 0; j2 < M2; j2 += nthreads, i++) {
-            const float2 wa = cmul(twa, tw_step[0][i]), wb = cmul(twb, tw_step[1][i]);
-            const Cx2 g = mul2c(lds_get(A4 + j2), Cx2{ v2f{ wa.x, wb.x }, v2f{ wa.y, wb.y } });
-            go[(size_t)pa * M2 + j2] = make_float2(g.re.x, g.im.x);
-            if (!self) go[(size_t)pb * M2 + j2] = make_float2(g.re.y, g.im.y);
-        }
+        Cx2 gout[ASX_ROW_STEPS];
+        static_for<0, ASX_ROW_STEPS>([&](auto I) __attribute__((always_inline)) {
+            constexpr int i = decltype(I)::value;
+            const int j2 = threadIdx.x + i * nthreads;
+            gout[i] = lds_get(A4 + (j2 < M2 ? j2 : 0));
+        });
+        static_for<0, ASX_ROW_STEPS>([&](auto I) __attribute__((always_inline)) {
+            constexpr int i = decltype(I)::value;
+            const int j2 = threadIdx.x + i * nthreads;
+            if (j2 < M2) {
+                const float2 wa = cmul(twa, tw_step[0][i]), wb = cmul(twb, tw_step[1][i]);
+                const Cx2 g = mul2c(gout[i], Cx2{ v2f{ wa.x, wb.x }, v2f{ wa.y, wb.y } });
+                go[(size_t)pa * M2 + j2] = make_float2(g.re.x, g.im.x);
+                if (!self) go[(size_t)pb * M2 + j2] = make_float2(g.re.y, g.im.y);
+            }
+        });
         ASX_STAMP(5);
     }
 }
