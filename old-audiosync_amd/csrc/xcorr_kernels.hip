@@ -251,6 +251,10 @@ __device__ __forceinline__ void combine_pair(Cx2 Za, Cx2 Zb, float2 w2, float2 &
 struct RowRegs {
     float2 xa[ASX_ROW_STEPS], ya[ASX_ROW_STEPS], xb[ASX_ROW_STEPS], yb[ASX_ROW_STEPS];
 };
+#define ASX_ROW_WSTEPS ((ASX_ROW_STEPS + 1) / 2) // steps of the 16-byte form: two elements per lane and step
+struct RowRegsWide {
+    float4 xa[ASX_ROW_WSTEPS], ya[ASX_ROW_WSTEPS], xb[ASX_ROW_WSTEPS], yb[ASX_ROW_WSTEPS];
+};
 
 // S2 = void: schedule of the row transforms read from the plan at run time (any length);
 // S2 = Sched<M2, radices...>: compiled in (the production lengths, see asx_launch_rows).
@@ -289,52 +293,93 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, ASX_ROWS_MIN_WAVES) void k_row
         LdsLayout Li;
         Li.ngroups = 1; Li.log_ngroups = 0;
         Li.elem_stride = 1; Li.group_stride = 0; Li.nthreads = nthreads;
-        // every row load of the thread is issued first; the twiddle lookups below overlap them
+        // Every row load of the thread is issued first; the twiddle lookups below overlap them.
+        // Rows of even length move as 16 bytes per lane (two complex values): a block's burst of
+        // 8-byte loads takes 2-3x as long to come back (tools/micro/rowload_latency.hip: 21 k cycles
+        // against 8-12 k for the same four rows).
+        const bool wide = (M2 & 1) == 0;
+        const int half = M2 >> 1; // wide: a thread owns the element pairs q = t + nthreads*i, j2 = 2q, 2q+1
         RowRegs L;
+        RowRegsWide LW;
         {
             const float2 *gx = zxa + (size_t)pair * M, *gy = zya + (size_t)pair * M;
-            static_for<0, ASX_ROW_STEPS>([&](auto I) __attribute__((always_inline)) {
-                const int j2 = threadIdx.x + decltype(I)::value * nthreads;
-                L.xa[I] = L.ya[I] = L.xb[I] = L.yb[I] = make_float2(0.f, 0.f);
-                if (j2 < M2) {
-                    L.xa[I] = gx[(size_t)pa * M2 + j2];
-                    L.ya[I] = gy[(size_t)pa * M2 + j2];
-                    if (!self) {
-                        L.xb[I] = gx[(size_t)pb * M2 + j2];
-                        L.yb[I] = gy[(size_t)pb * M2 + j2];
+            if (wide) {
+                static_for<0, ASX_ROW_WSTEPS>([&](auto I) __attribute__((always_inline)) {
+                    const int q = threadIdx.x + decltype(I)::value * nthreads;
+                    LW.xa[I] = LW.ya[I] = LW.xb[I] = LW.yb[I] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (q < half) {
+                        LW.xa[I] = *reinterpret_cast<const float4 *>(gx + (size_t)pa * M2 + 2 * q);
+                        LW.ya[I] = *reinterpret_cast<const float4 *>(gy + (size_t)pa * M2 + 2 * q);
+                        if (!self) {
+                            LW.xb[I] = *reinterpret_cast<const float4 *>(gx + (size_t)pb * M2 + 2 * q);
+                            LW.yb[I] = *reinterpret_cast<const float4 *>(gy + (size_t)pb * M2 + 2 * q);
+                        }
                     }
-                }
-            });
+                });
+            } else {
+                static_for<0, ASX_ROW_STEPS>([&](auto I) __attribute__((always_inline)) {
+                    const int j2 = threadIdx.x + decltype(I)::value * nthreads;
+                    L.xa[I] = L.ya[I] = L.xb[I] = L.yb[I] = make_float2(0.f, 0.f);
+                    if (j2 < M2) {
+                        L.xa[I] = gx[(size_t)pa * M2 + j2];
+                        L.ya[I] = gy[(size_t)pa * M2 + j2];
+                        if (!self) {
+                            L.xb[I] = gx[(size_t)pb * M2 + j2];
+                            L.yb[I] = gy[(size_t)pb * M2 + j2];
+                        }
+                    }
+                });
+            }
         }
         TwPre pre_f;
         if constexpr (STATIC) pre_f = tw_prefetch_first<S2, false, false>(Lf, P.tw2);
         else pre_f = tw_prefetch<false>(PD.st2, 0, Lf, P.tw2);
 
-        // Four-step twiddle of row k1: w_M^(k1*j2) with j2 = t + blockDim*i factors into
-        // w_M^(k1*t) (one two-level lookup per thread) times w_M^(k1*blockDim*i) (a handful per block).
-        const int nsteps = (M2 + nthreads - 1) / nthreads; // <= ASX_ROW_STEPS (launcher)
+        // Four-step twiddle of row k1: w_M^(k1*j2).  With j2 = c*(t + nthreads*i) + h (c = 2, h = 0/1
+        // for the wide form; c = 1, h = 0 otherwise) it factors into w_M^(k1*c*t) (one two-level
+        // lookup per thread), w_M^(k1*c*nthreads*i) (a handful per block) and w_M^(k1*h) (block-uniform).
+        const int cw = wide ? 2 : 1;
+        const int nsteps = wide ? (half + nthreads - 1) / nthreads : (M2 + nthreads - 1) / nthreads; // <= ASX_ROW_STEPS (launcher)
         if ((int)threadIdx.x < 2 * nsteps) {
             const int which = (int)threadIdx.x >= nsteps;
             const int i = threadIdx.x - which * nsteps;
             const uint32_t row = which ? (uint32_t)m1 : (uint32_t)k1;
-            tw_step[which][i] = tw_F(P, 2u * row * (uint32_t)(i * nthreads));
+            tw_step[which][i] = tw_F(P, 2u * row * (uint32_t)(cw * i * nthreads));
         }
-        const uint32_t tcol = threadIdx.x < (unsigned)M2 ? threadIdx.x : 0u;
+        const uint32_t tcol = (uint32_t)cw * threadIdx.x < (unsigned)M2 ? (uint32_t)cw * threadIdx.x : 0u;
         const float2 twa = tw_F(P, 2u * (uint32_t)k1 * tcol);
         const float2 twb = tw_F(P, 2u * (uint32_t)m1 * tcol);
+        const float2 wk1 = tw_F(P, 2u * (uint32_t)k1), wm1 = tw_F(P, 2u * (uint32_t)m1); // w_M^k1, w_M^m1
         {
             __syncthreads();
-            static_for<0, ASX_ROW_STEPS>([&](auto I) __attribute__((always_inline)) {
-                constexpr int i = decltype(I)::value;
-                const int j2 = threadIdx.x + i * nthreads;
-                if (j2 < M2) {
-                    lds_put(A4 + j2, mulw(Cx2{ v2f{ L.xa[I].x, L.ya[I].x }, v2f{ L.xa[I].y, L.ya[I].y } },
-                                          cmul(twa, tw_step[0][i])));
-                    if (!self)
-                        lds_put(B4 + j2, mulw(Cx2{ v2f{ L.xb[I].x, L.yb[I].x }, v2f{ L.xb[I].y, L.yb[I].y } },
-                                              cmul(twb, tw_step[1][i])));
-                }
-            });
+            if (wide) {
+                static_for<0, ASX_ROW_WSTEPS>([&](auto I) __attribute__((always_inline)) {
+                    constexpr int i = decltype(I)::value;
+                    const int q = threadIdx.x + i * nthreads;
+                    if (q < half) {
+                        const float2 wa0 = cmul(twa, tw_step[0][i]), wa1 = cmul(wa0, wk1);
+                        lds_put(A4 + 2 * q, mulw(Cx2{ v2f{ LW.xa[I].x, LW.ya[I].x }, v2f{ LW.xa[I].y, LW.ya[I].y } }, wa0));
+                        lds_put(A4 + 2 * q + 1, mulw(Cx2{ v2f{ LW.xa[I].z, LW.ya[I].z }, v2f{ LW.xa[I].w, LW.ya[I].w } }, wa1));
+                        if (!self) {
+                            const float2 wb0 = cmul(twb, tw_step[1][i]), wb1 = cmul(wb0, wm1);
+                            lds_put(B4 + 2 * q, mulw(Cx2{ v2f{ LW.xb[I].x, LW.yb[I].x }, v2f{ LW.xb[I].y, LW.yb[I].y } }, wb0));
+                            lds_put(B4 + 2 * q + 1, mulw(Cx2{ v2f{ LW.xb[I].z, LW.yb[I].z }, v2f{ LW.xb[I].w, LW.yb[I].w } }, wb1));
+                        }
+                    }
+                });
+            } else {
+                static_for<0, ASX_ROW_STEPS>([&](auto I) __attribute__((always_inline)) {
+                    constexpr int i = decltype(I)::value;
+                    const int j2 = threadIdx.x + i * nthreads;
+                    if (j2 < M2) {
+                        lds_put(A4 + j2, mulw(Cx2{ v2f{ L.xa[I].x, L.ya[I].x }, v2f{ L.xa[I].y, L.ya[I].y } },
+                                              cmul(twa, tw_step[0][i])));
+                        if (!self)
+                            lds_put(B4 + j2, mulw(Cx2{ v2f{ L.xb[I].x, L.yb[I].x }, v2f{ L.xb[I].y, L.yb[I].y } },
+                                                  cmul(twb, tw_step[1][i])));
+                    }
+                });
+            }
         }
         __syncthreads();
         ASX_STAMP(1);
@@ -345,7 +390,7 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, ASX_ROWS_MIN_WAVES) void k_row
         // ---- spectral combine.  Every thread first computes its G values into registers (it
         // reads slots other threads will overwrite), then, after a barrier, scatters them:
         // G[k] -> C[sa] member 0, G[M-k] -> C[sb] member 1 (member 0 for self-paired rows).
-        const float2 wA = tw_F(P, 2u * (uint32_t)k1); // w_M^k1, block-uniform; w_M^(k1 + M1*k2) = wA * w_M2^k2
+        const float2 wA = wk1; // w_M^k1, block-uniform; w_M^(k1 + M1*k2) = wA * w_M2^k2
         float2 gk[ASX_ROW_STEPS], gm[ASX_ROW_STEPS];
         int sa[ASX_ROW_STEPS], sb[ASX_ROW_STEPS]; // -1: nothing to write
         if (!self) {
@@ -431,24 +476,49 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, ASX_ROWS_MIN_WAVES) void k_row
 
         // inverse four-step twiddle conj(w_M^(k1*j2)) / conj(w_M^(m1*j2)), one per member; unrolled so
         // that the LDS reads of all steps are in flight together (a rolled loop pays the LDS latency
-        // once per step).  twa / twb ride in registers from the load phase.
+        // once per step).  twa / twb ride in registers from the load phase.  Even rows leave as 16
+        // bytes per lane, like they came.
         float2 *go = ga + (size_t)pair * M;
-        Cx2 gout[ASX_ROW_STEPS];
-        static_for<0, ASX_ROW_STEPS>([&](auto I) __attribute__((always_inline)) {
-            constexpr int i = decltype(I)::value;
-            const int j2 = threadIdx.x + i * nthreads;
-            gout[i] = lds_get(A4 + (j2 < M2 ? j2 : 0));
-        });
-        static_for<0, ASX_ROW_STEPS>([&](auto I) __attribute__((always_inline)) {
-            constexpr int i = decltype(I)::value;
-            const int j2 = threadIdx.x + i * nthreads;
-            if (j2 < M2) {
-                const float2 wa = cmul(twa, tw_step[0][i]), wb = cmul(twb, tw_step[1][i]);
-                const Cx2 g = mul2c(gout[i], Cx2{ v2f{ wa.x, wb.x }, v2f{ wa.y, wb.y } });
-                go[(size_t)pa * M2 + j2] = make_float2(g.re.x, g.im.x);
-                if (!self) go[(size_t)pb * M2 + j2] = make_float2(g.re.y, g.im.y);
-            }
-        });
+        if (wide) {
+            Cx2 g0[ASX_ROW_WSTEPS], g1[ASX_ROW_WSTEPS];
+            static_for<0, ASX_ROW_WSTEPS>([&](auto I) __attribute__((always_inline)) {
+                constexpr int i = decltype(I)::value;
+                const int q = threadIdx.x + i * nthreads;
+                const int qq = q < half ? q : 0;
+                g0[i] = lds_get(A4 + 2 * qq);
+                g1[i] = lds_get(A4 + 2 * qq + 1);
+            });
+            static_for<0, ASX_ROW_WSTEPS>([&](auto I) __attribute__((always_inline)) {
+                constexpr int i = decltype(I)::value;
+                const int q = threadIdx.x + i * nthreads;
+                if (q < half) {
+                    const float2 wa0 = cmul(twa, tw_step[0][i]), wb0 = cmul(twb, tw_step[1][i]);
+                    const float2 wa1 = cmul(wa0, wk1), wb1 = cmul(wb0, wm1);
+                    const Cx2 h0 = mul2c(g0[i], Cx2{ v2f{ wa0.x, wb0.x }, v2f{ wa0.y, wb0.y } });
+                    const Cx2 h1 = mul2c(g1[i], Cx2{ v2f{ wa1.x, wb1.x }, v2f{ wa1.y, wb1.y } });
+                    *reinterpret_cast<float4 *>(go + (size_t)pa * M2 + 2 * q) = make_float4(h0.re.x, h0.im.x, h1.re.x, h1.im.x);
+                    if (!self)
+                        *reinterpret_cast<float4 *>(go + (size_t)pb * M2 + 2 * q) = make_float4(h0.re.y, h0.im.y, h1.re.y, h1.im.y);
+                }
+            });
+        } else {
+            Cx2 gout[ASX_ROW_STEPS];
+            static_for<0, ASX_ROW_STEPS>([&](auto I) __attribute__((always_inline)) {
+                constexpr int i = decltype(I)::value;
+                const int j2 = threadIdx.x + i * nthreads;
+                gout[i] = lds_get(A4 + (j2 < M2 ? j2 : 0));
+            });
+            static_for<0, ASX_ROW_STEPS>([&](auto I) __attribute__((always_inline)) {
+                constexpr int i = decltype(I)::value;
+                const int j2 = threadIdx.x + i * nthreads;
+                if (j2 < M2) {
+                    const float2 wa = cmul(twa, tw_step[0][i]), wb = cmul(twb, tw_step[1][i]);
+                    const Cx2 g = mul2c(gout[i], Cx2{ v2f{ wa.x, wb.x }, v2f{ wa.y, wb.y } });
+                    go[(size_t)pa * M2 + j2] = make_float2(g.re.x, g.im.x);
+                    if (!self) go[(size_t)pb * M2 + j2] = make_float2(g.re.y, g.im.y);
+                }
+            });
+        }
         ASX_STAMP(5);
     }
 }
