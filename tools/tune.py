@@ -50,6 +50,10 @@ for n in lengths:
         res.append((batch / dt, "%dx%dx%d" % plan.split, plan.threads, ok, sp is None))
         plan.close()
     res.sort(reverse=True)
+    if os.environ.get("TUNE_DUMP"):   # every candidate, machine-readable (input of the planner's cost model fit)
+        for r in res:
+            d = asx.planmath_describe(n, None if r[4] else r[1])
+            print("DUMP %d %s %.1f %s %s %d" % (n, r[1], r[0], ",".join(map(str, d["radix1"])), ",".join(map(str, d["radix2"])), int(r[4])))
     print("N=%d batch=%d" % (n, batch))
     for r in res[:6]:
         print("   %9.0f /s  %-14s threads=%s ok=%s%s" % (r[0], r[1], r[2], r[3], "  <- planner default" if r[4] else ""))
