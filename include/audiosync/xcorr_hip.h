@@ -60,8 +60,12 @@ int asx_abi_version(void);
  * fit the LDS kernels (N up to about 4,000,000).  Lengths 2N that are not
  * {2,3,5}-smooth are embedded in a longer smooth transform (same r[k]). */
 asx_plan *asx_plan_create(size_t sample_len, size_t max_batch, int device);
-/* Same, with the transform split forced: "M1xM2xT" (M1*M2 = F/2, T = tile
- * columns, a power of two <= 64).  NULL or "" = automatic (or $ASX_SPLIT). */
+/* Same, with the transform split chosen by the caller: "M1xM2xT" (M1*M2 = F/2, T = tile
+ * columns, a power of two <= 64) forces it; "measure" times the planner's best candidates
+ * on the device (synthetic pairs, a fraction of a second) and keeps the fastest -- what
+ * FFTW_MEASURE is to the FFTW_ESTIMATE of src/cross_correlation.c:187-201; NULL, "" or
+ * "auto" = the planner's cost model (tuned table for the reference's six lengths).
+ * $ASX_SPLIT supplies the value when the argument is NULL or "". */
 asx_plan *asx_plan_create_ex(size_t sample_len, size_t max_batch, int device, const char *split);
 void asx_plan_destroy(asx_plan *plan);
 

@@ -123,7 +123,6 @@ template <typename T> static int dev_upload(asx_plan *p, const T **out, const st
 
 static int plan_init(asx_plan *p, size_t N, size_t max_batch, const char *split)
 {
-    if (!split || !*split) split = getenv("ASX_SPLIT");
     std::string err = asx_host_plan_build(N, split, &p->host);
     if (!err.empty()) return fail("plan for sample_len=%zu: %s", N, err.c_str());
     const AsxHostPlan &h = p->host;
@@ -188,8 +187,79 @@ static int plan_init(asx_plan *p, size_t N, size_t max_batch, const char *split)
     return 0;
 }
 
+// Measured mode (what FFTW_MEASURE is to FFTW_ESTIMATE): the planner's cost model is only a model --
+// for lengths outside its tuned table its pick was up to 27 % slower than the best split -- so time
+// its cheapest candidates (plus its own pick) on the device, on synthetic pairs, and return the
+// fastest.  About 20 plans are built and run; a fraction of a second per sample length.
+static std::string measure_best_split(size_t N, size_t max_batch, int device)
+{
+    std::vector<std::string> cands = asx_host_plan_candidates(N, 16);
+    {
+        AsxHostPlan h;
+        if (asx_host_plan_build(N, "", &h).empty()) {
+            char buf[64];
+            snprintf(buf, sizeof buf, "%dx%dx%d", h.M1, h.M2, h.T);
+            if (std::find(cands.begin(), cands.end(), std::string(buf)) == cands.end()) cands.insert(cands.begin(), buf);
+        }
+    }
+    if (cands.empty()) return "";
+    size_t probe = ((size_t)512 << 20) / (12 * N); // at most 512 MB of float32 inputs
+    probe = std::max<size_t>(probe, 4);
+    probe = std::min<size_t>(probe, 1024);
+    probe = std::max<size_t>(1, std::min(probe, max_batch));
+    float *d_src = nullptr, *d_smp = nullptr;
+    int64_t *d_lag = nullptr;
+    double *d_coef = nullptr;
+    int32_t *d_ret = nullptr;
+    std::string best;
+    float best_ms = 0.f;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (hipMalloc(&d_src, probe * 2 * N * sizeof(float)) == hipSuccess && hipMalloc(&d_smp, probe * N * sizeof(float)) == hipSuccess &&
+        hipMalloc(&d_lag, probe * sizeof(int64_t)) == hipSuccess && hipMalloc(&d_coef, probe * sizeof(double)) == hipSuccess &&
+        hipMalloc(&d_ret, probe * sizeof(int32_t)) == hipSuccess && hipEventCreate(&e0) == hipSuccess &&
+        hipEventCreate(&e1) == hipSuccess &&
+        asx_synth_pairs_dev(12345, 0, probe, N, 1, d_src, d_smp, nullptr, nullptr) == 0 && hipDeviceSynchronize() == hipSuccess) {
+        for (const std::string &c : cands) {
+            asx_plan *p = asx_plan_create_ex(N, probe, device, c.c_str());
+            if (!p) continue;
+            bool ok = asx_xcorr_batch_f32_dev(p, d_src, d_smp, probe, d_lag, d_coef, d_ret, nullptr) == 0; // warm-up
+            float ms = 0.f;
+            if (ok) {
+                ok = hipEventRecord(e0, p->stream) == hipSuccess;
+                for (int r = 0; r < 2 && ok; r++) ok = asx_xcorr_batch_f32_dev(p, d_src, d_smp, probe, d_lag, d_coef, d_ret, nullptr) == 0;
+                ok = ok && hipEventRecord(e1, p->stream) == hipSuccess && hipEventSynchronize(e1) == hipSuccess &&
+                     hipEventElapsedTime(&ms, e0, e1) == hipSuccess;
+            }
+            asx_plan_destroy(p);
+            if (ok && (best.empty() || ms < best_ms)) { best = c; best_ms = ms; }
+        }
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipFree(d_src); (void)hipFree(d_smp); (void)hipFree(d_lag); (void)hipFree(d_coef); (void)hipFree(d_ret);
+    (void)hipGetLastError();
+    return best;
+}
+
 extern "C" asx_plan *asx_plan_create_ex(size_t sample_len, size_t max_batch, int device, const char *split)
 {
+    if (!split || !*split) split = getenv("ASX_SPLIT");
+    if (split && !strcmp(split, "measure")) {
+        int prev = 0, ndev0 = 0;
+        if (hipGetDeviceCount(&ndev0) != hipSuccess || ndev0 == 0) {
+            fail("no usable HIP device; this library has no CPU fallback");
+            return nullptr;
+        }
+        HIP_TRY_NULL(hipGetDevice(&prev));
+        const int dev = device < 0 ? prev : device;
+        if (dev >= ndev0) { fail("device %d out of range (%d devices)", dev, ndev0); return nullptr; }
+        HIP_TRY_NULL(hipSetDevice(dev));
+        const std::string best = measure_best_split(sample_len, max_batch ? max_batch : 1, dev);
+        (void)hipSetDevice(prev);
+        // an empty result (nothing could be timed) falls back to the planner's own choice
+        return asx_plan_create_ex(sample_len, max_batch, device, best.empty() ? "auto" : best.c_str());
+    }
+    if (split && !strcmp(split, "auto")) split = "";
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev == 0) {
@@ -739,6 +809,17 @@ extern "C" int asx_planmath_describe(size_t sample_len, const char *split, uint3
     for (int i = 0; i < h.st1.nstages; i++) radix1[i] = h.st1.radix[i];
     for (int i = 0; i < h.st2.nstages; i++) radix2[i] = h.st2.radix[i];
     return 0;
+}
+
+// candidates of the measured mode, newline-separated "M1xM2xT" strings; returns their number
+extern "C" int asx_planmath_candidates(size_t sample_len, size_t max_count, char *out, size_t cap)
+{
+    const std::vector<std::string> c = asx_host_plan_candidates(sample_len, max_count);
+    std::string joined;
+    for (const std::string &x : c) { joined += x; joined += '\n'; }
+    if (joined.size() + 1 > cap) return fail("candidate list larger than buffer");
+    memcpy(out, joined.c_str(), joined.size() + 1);
+    return (int)c.size();
 }
 
 // tables: which = 0 pos1_of_k1 (M1 ints), 1 k1_of_pos1 (M1), 2 pos2_of_k2 (M2)

@@ -133,6 +133,48 @@ static int tile_for(int M1)
     return T;
 }
 
+// transform length for sample_len N: 2N if that is {2,3,5}-smooth, else the next smooth even
+// length >= 3N-1 (embedding, see asx_host_plan_build)
+static uint64_t transform_len(size_t N)
+{
+    const uint64_t F = 2 * (uint64_t)N;
+    return asx_is_smooth(F) ? F : asx_next_smooth_even(3 * (uint64_t)N - 1);
+}
+
+std::vector<std::string> asx_host_plan_candidates(size_t N, size_t max_count)
+{
+    std::vector<std::pair<double, std::string>> all;
+    if (N == 0 || N > (size_t)1 << 27) return {};
+    const uint64_t F = transform_len(N);
+    if (F >= (1ull << 31)) return {};
+    const uint32_t M = (uint32_t)(F / 2);
+    const int rows_max = (int)(ASX_LDS_ROWS_MAX / (4 * sizeof(float2)));
+    for (uint32_t a = 1; a <= M && a <= 8192u; a++) {
+        if (M % a) continue;
+        const uint32_t b = M / a;
+        if ((int)b > rows_max) continue;
+        AsxStages s1, s2;
+        if (!asx_make_stages((int)a, &s1) || !asx_make_stages((int)b, &s2)) continue;
+        int maxr = 2;
+        for (int i = 0; i < s1.nstages; i++) maxr = std::max(maxr, s1.radix[i]);
+        for (int i = 0; i < s2.nstages; i++) maxr = std::max(maxr, s2.radix[i]);
+        const int tmax = tile_for((int)a);
+        for (int t = 2; t <= tmax; t <<= 1) {
+            if ((uint32_t)t > b && t > 2) continue;
+            if (t < 8 && tmax >= 8) continue; // narrow tiles only where nothing wider fits
+            const double lds = (double)std::max((size_t)a * t * sizeof(float2), (size_t)4 * b * sizeof(float2)) / 1024.0;
+            const double cost = lds + 8.0 * (s1.nstages + s2.nstages) + (maxr > 12 ? 20.0 : 0.0);
+            char buf[64];
+            snprintf(buf, sizeof buf, "%ux%ux%d", a, b, t);
+            all.emplace_back(cost, buf);
+        }
+    }
+    std::sort(all.begin(), all.end());
+    std::vector<std::string> out;
+    for (size_t i = 0; i < all.size() && out.size() < max_count; i++) out.push_back(all[i].second);
+    return out;
+}
+
 std::string asx_host_plan_build(size_t N, const char *split_override, AsxHostPlan *hp)
 {
     if (N == 0) return "sample_len must be > 0";

@@ -29,5 +29,9 @@ uint64_t asx_next_smooth_even(uint64_t n);
 // Fills *plan for sample_len N. `split_override` may be "" or "M1xM2xT".
 // Returns "" on success, else an error message.
 std::string asx_host_plan_build(size_t N, const char *split_override, AsxHostPlan *plan);
+// The `max_count` cheapest splits of sample_len N by the planner's cost model, every feasible tile
+// width included ("M1xM2xT" strings, cheapest first): the candidates of the measured mode
+// (asx_plan_create_ex(..., "measure") times them on the device and keeps the fastest).
+std::vector<std::string> asx_host_plan_candidates(size_t N, size_t max_count);
 bool asx_make_stages(int n, AsxStages *st);
 std::vector<int> asx_position_table(const AsxStages &st); // pos[k] = slot of X[k] after the DIF transform

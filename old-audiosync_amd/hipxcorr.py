@@ -155,6 +155,18 @@ def planmath_describe(sample_len, split=None):
             "radix1": list(r1[: n1.value]), "radix2": list(r2[: n2.value])}
 
 
+def planmath_candidates(sample_len, max_count=16):
+    """host-only: the splits the measured mode (split="measure") would time, cheapest first."""
+    buf = ctypes.create_string_buffer(64 * max_count + 1)
+    L = lib()
+    L.asx_planmath_candidates.restype = ctypes.c_int
+    L.asx_planmath_candidates.argtypes = [ctypes.c_size_t, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t]
+    n = L.asx_planmath_candidates(sample_len, max_count, buf, len(buf))
+    if n < 0:
+        raise AsxError(_err())
+    return [x for x in buf.value.decode().split("\n") if x]
+
+
 def planmath_table(sample_len, which, split=None):
     d = planmath_describe(sample_len, split)
     cap = max(d["M1"], d["M2"])

@@ -567,3 +567,19 @@ def test_generic_kernels_agree_with_compiled_in_schedules(mod):
             o_ret, o_lag, o_coef = oracle.cross_correlation(s, t)
             assert got["static"][n]["lag"][p] == o_lag and got["static"][n]["ret"][p] == o_ret
             assert abs(got["static"][n]["coef"][p] - o_coef) < COEF_TOL
+
+
+def test_measured_mode_plan_matches_oracle(mod):
+    """split="measure": the planner's candidates are timed on the device and the fastest is kept
+    (xcorr_hip.h).  Whatever it picks, the answers are the oracle's."""
+    n = 96000          # not in the tuned table: the model and the measurement disagree here
+    pairs = [oracle.synth_pair(31, p, n, 0) for p in range(3)]
+    src = np.stack([p[0] for p in pairs])
+    smp = np.stack([p[1] for p in pairs])
+    with mod.Plan(n, 3, 0, split="measure") as plan:
+        assert "%dx%dx%d" % plan.split in mod.planmath_candidates(n, 16) + ["%dx%dx%d" % (lambda d: (d["M1"], d["M2"], d["T"]))(mod.planmath_describe(n))]
+        lag, coef, ret = plan.xcorr_batch_f32(src, smp)
+    for i, (s, t, _) in enumerate(pairs):
+        o_ret, o_lag, o_coef = oracle.cross_correlation(s, t)
+        assert int(ret[i]) == o_ret and int(lag[i]) == o_lag
+        assert abs(float(coef[i]) - o_coef) < COEF_TOL

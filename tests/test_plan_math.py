@@ -91,3 +91,17 @@ def test_unsupported_lengths_are_rejected_with_a_message():
     # a huge prime sample_len embeds into a smooth length that must still split into LDS-sized factors
     d = mod.planmath_describe(3999971)
     assert d["F"] >= 3 * 3999971 - 1 and d["M1"] * d["M2"] * 2 == d["F"]
+
+
+@pytest.mark.parametrize("n", [45, 1000, 44100, 96000, 1000000, 1440000])
+def test_measured_mode_candidates_are_valid_splits(n):
+    mod = asx()
+    base = mod.planmath_describe(n)
+    cands = mod.planmath_candidates(n, 16)
+    assert 1 <= len(cands) <= 16 and len(set(cands)) == len(cands)
+    for c in cands:
+        d = mod.planmath_describe(n, c)          # every candidate must be accepted as an explicit split
+        m1, m2, t = (int(x) for x in c.split("x"))
+        assert (d["M1"], d["M2"], d["T"]) == (m1, m2, t)
+        assert m1 * m2 * 2 == base["F"] and d["F"] == base["F"]
+        assert t >= 2 and (t & (t - 1)) == 0 and m1 * t * 8 <= 80 * 1024 and 4 * m2 * 8 <= 64 * 1024
