@@ -153,7 +153,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # ASX_BENCH_FORCE_DIST=1: take the multi-rank code path (process group, result gather) with a single
+    # rank too -- the only way to exercise it on a one-GPU box (launch under torch.distributed.run)
+    multi = world > 1 or os.environ.get("ASX_BENCH_FORCE_DIST") == "1"
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -166,9 +169,11 @@ def main():
     d_src = torch.empty(batch * 2 * n, dtype=torch.float32, device=dev)
     d_smp = torch.empty(batch * n, dtype=torch.float32, device=dev)
     d_true = torch.empty(batch, dtype=torch.int64, device=dev)
-    d_lag = torch.zeros(batch, dtype=torch.int64, device=dev)
-    d_coef = torch.zeros(batch, dtype=torch.float64, device=dev)
-    d_ret = torch.zeros(batch, dtype=torch.int32, device=dev)
+    # a shard's results live back to back in one byte buffer so that the gather is ONE collective with
+    # no packing kernels (sharding.result_buffer)
+    res_buf, (d_lag, d_coef, d_ret) = sharding.result_buffer(batch, dev)
+    gather_out = torch.empty((world, sharding.result_bytes(batch)), dtype=torch.uint8, device=dev) if multi else None
+    gathered = [None]
     stream = torch.cuda.current_stream().cuda_stream
     # distinct pairs on every rank: pair ids [rank*batch, (rank+1)*batch)
     asx.synth_pairs_dev(20260101, rank * batch, batch, n, args.noise_shift, d_src.data_ptr(),
@@ -178,31 +183,35 @@ def main():
     def step():
         plan.xcorr_batch_dev(d_src.data_ptr(), d_smp.data_ptr(), batch, d_lag.data_ptr(),
                              d_coef.data_ptr(), d_ret.data_ptr(), stream)
-        if world > 1:
-            # the only exchange on this path: RCCL all-gather of (lag, coef, ret) of every shard
-            sharding.gather_results(d_lag, d_coef, d_ret, batch * world)
+        if multi:
+            # the only exchange on this path: RCCL all-gather of the 20 result bytes per pair of every
+            # shard, in stream order behind the kernels that produce them
+            gathered[0] = sharding.gather_result_buffers(res_buf, batch, out=gather_out)
 
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
     # correctness of what was timed: the planted delays
     ok = bool(torch.equal(d_lag, d_true)) and int(d_ret.abs().sum()) == 0
+    if multi and gathered[0] is not None:   # ... and this rank's slice of what the gather delivered
+        views = gathered[0][1]
+        ok = ok and len(views) == world and bool(torch.equal(views[rank][0], d_true))
 
     # per-kernel durations, HIP events on the stream the kernels ran on (one extra profiled step)
     plan.set_profiling(True)
@@ -266,7 +275,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(n)
         print(json.dumps(line), flush=True)
     plan.close()
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

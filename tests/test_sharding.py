@@ -69,3 +69,35 @@ def test_gather_over_gloo(tmp_path, world, total):
         assert lag.tolist() == [e[1] for e in expect]          # every rank holds the full batch, in order
         assert ret.tolist() == [e[0] for e in expect]
         assert np.allclose(coef, [e[2] for e in expect], rtol=0, atol=0)
+
+
+def _worker_buffers(rank, world, port, count, n, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    graft.load()
+    from audiosync_amd import sharding
+    buf, (lag, coef, ret) = sharding.result_buffer(count, "cpu")     # what bench.py hands to the library
+    assert buf.numel() == sharding.result_bytes(count) >= 20 * count and lag.dtype == torch.int64 and coef.dtype == torch.float64 and ret.dtype == torch.int32
+    for i in range(count):
+        src, smp, _ = oracle.synth_pair(9, rank * count + i, n, 0)
+        r, l, c = oracle.cross_correlation(src, smp)
+        lag[i], coef[i], ret[i] = l, c, r                            # written through the views = into the buffer
+    out, views = sharding.gather_result_buffers(buf, count)
+    assert out.shape == (world, sharding.result_bytes(count)) and len(views) == world
+    np.save(os.path.join(out_dir, "blag%d.npy" % rank), torch.cat([v[0] for v in views]).numpy())
+    np.save(os.path.join(out_dir, "bcoef%d.npy" % rank), torch.cat([v[1] for v in views]).numpy())
+    np.save(os.path.join(out_dir, "bret%d.npy" % rank), torch.cat([v[2] for v in views]).numpy())
+    dist.destroy_process_group()
+
+
+def test_byte_buffer_gather_over_gloo(tmp_path):
+    """bench.py's gather for equal shards: results of a shard back to back in one byte buffer, one collective."""
+    world, count, n = 2, 3, 2000
+    port = free_port()
+    mp.spawn(_worker_buffers, args=(world, port, count, n, str(tmp_path)), nprocs=world, join=True)
+    expect = [oracle.cross_correlation(*oracle.synth_pair(9, p, n, 0)[:2]) for p in range(world * count)]
+    for r in range(world):
+        assert np.load(tmp_path / ("blag%d.npy" % r)).tolist() == [e[1] for e in expect]
+        assert np.load(tmp_path / ("bret%d.npy" % r)).tolist() == [e[0] for e in expect]
+        assert np.array_equal(np.load(tmp_path / ("bcoef%d.npy" % r)), np.array([e[2] for e in expect]))
