@@ -19,7 +19,7 @@
 #define ASX_THREADS 256                     // block size of the streaming kernels
 #define ASX_FFT_THREADS_MAX 512             // upper bound for the three transform kernels
 #define ASX_COL_LOADS 10                    // tile loads a thread keeps in flight in the column kernels
-#define ASX_ROW_STEPS 5                     // max ceil(M2 / blockDim) in k_rows (register-staged combine)
+#define ASX_ROW_STEPS 5                     // max ceil(M2 / blockDim) in k_rows (bins a thread owns in the load / combine / store phases)
 #define ASX_PEARSON_BLOCKS 64               // partial-sum blocks per pair
 // Peak refinement: every lag whose float32 |r| is within ASX_REFINE_EPS (relative) of the
 // float32 maximum is re-evaluated exactly (float64 dot product of the inputs) and the

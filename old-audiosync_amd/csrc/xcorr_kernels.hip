@@ -37,7 +37,7 @@
 #define ASX_STAMP(slot) ASX_STAMP_AT(0, task, slot)
 
 #ifndef ASX_ROWS_MIN_WAVES
-#define ASX_ROWS_MIN_WAVES 4   // k_rows fits 128 VGPRs (112 with radix 12, scalar arithmetic): four blocks per CU
+#define ASX_ROWS_MIN_WAVES 4   // k_rows fits 128 VGPRs (92-119 by variant): four blocks per CU, which is also what its LDS allows
 #endif
 
 extern __shared__ __attribute__((aligned(16))) float2 asx_lds[];
