@@ -938,14 +938,25 @@ __global__ __launch_bounds__(ASX_THREADS) void k_pearson_partial(const TIn *__re
     const TIn *x = src + pair * src_pitch + s.src_off;
     const TIn *y = smp + pair * smp_pitch + s.smp_off;
     double sx = 0, sy = 0, sxy = 0, sxx = 0, syy = 0;
-    for (uint64_t i = lo + threadIdx.x; i < hi; i += ASX_THREADS) {
-        const double a = (double)x[i], b = (double)y[i];
+    auto add = [&](double a, double b) {
         sx += a;
         sy += b;
         sxy += a * b;
         sxx += a * a;
         syy += b * b;
+    };
+    // four consecutive elements per lane and step: 16-byte loads (the segments start at any element,
+    // so the vector type only promises element alignment), then the few elements that are left
+    typedef TIn vec4u __attribute__((ext_vector_type(4), aligned(sizeof(TIn))));
+    uint64_t i = lo + 4u * threadIdx.x;
+    for (; i + 3 < hi; i += 4u * ASX_THREADS) {
+        const vec4u a = *reinterpret_cast<const vec4u *>(x + i), b = *reinterpret_cast<const vec4u *>(y + i);
+        add((double)a.x, (double)b.x);
+        add((double)a.y, (double)b.y);
+        add((double)a.z, (double)b.z);
+        add((double)a.w, (double)b.w);
     }
+    for (; i < hi; i++) add((double)x[i], (double)y[i]); // only the lane that holds the ragged end
     double v[5] = { wave_sum(sx), wave_sum(sy), wave_sum(sxy), wave_sum(sxx), wave_sum(syy) };
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (lane == 0)
