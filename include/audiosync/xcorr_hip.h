@@ -45,6 +45,8 @@ typedef struct asx_plan asx_plan;
 
 /* Number of usable HIP devices (0 when there is none or the runtime fails). */
 int asx_device_count(void);
+/* The calling thread's current HIP device (-1 when the runtime fails): what device < 0 means below. */
+int asx_current_device(void);
 /* Last error message of the calling thread ("" if none). Never NULL. */
 const char *asx_last_error(void);
 /* ABI version of this header (bumped on any signature change). */
@@ -68,6 +70,16 @@ asx_plan *asx_plan_create(size_t sample_len, size_t max_batch, int device);
  * $ASX_SPLIT supplies the value when the argument is NULL or "". */
 asx_plan *asx_plan_create_ex(size_t sample_len, size_t max_batch, int device, const char *split);
 void asx_plan_destroy(asx_plan *plan);
+
+/* Peak search exactness (replaces max_abs_index(), src/cross_correlation.c:52-67, a float64 scan).
+ * The transforms run in float32; every lag whose float32 value is within the float32 error bound of
+ * the float32 maximum is re-evaluated exactly and the reference's rule is applied to the exact values,
+ * for up to asx_plan_peak_capacity() such lags per pair (2048..16384 by sample_len; all 2N lags for
+ * short tracks).  A pair with more near-ties than that (an all-zero correlation, or a signal periodic
+ * in that many lags) keeps the float32 argmax, and the event is counted: *count = number of such pairs
+ * since the plan was created.  Synchronises the plan's streams. */
+int asx_plan_peak_overflows(asx_plan *plan, uint64_t *count);
+size_t asx_plan_peak_capacity(const asx_plan *plan);
 
 /* Introspection (used by tests, bench and DESIGN.md's numbers). */
 size_t asx_plan_sample_len(const asx_plan *plan);
@@ -96,7 +108,10 @@ int asx_xcorr_batch_f32(asx_plan *plan, const float *source, const float *sample
 /* Same with everything already resident in this plan's device memory space.
  * All pointers are DEVICE pointers; `stream` is a hipStream_t (NULL = the
  * plan's own stream).  Asynchronous: results are valid after the stream is
- * synchronised.  source pairs are 2N floats apart, sample pairs N floats. */
+ * synchronised.  source pairs are 2N floats apart, sample pairs N floats.
+ * A plan's workspaces are shared by all its calls: use ONE stream at a time per plan
+ * (calls on different streams must be ordered by the caller, e.g. with events);
+ * concurrent work belongs on separate plans. */
 int asx_xcorr_batch_f32_dev(asx_plan *plan, const float *d_source, const float *d_sample,
                             size_t batch, int64_t *d_lag, double *d_coef, int32_t *d_ret,
                             void *stream);

@@ -50,13 +50,30 @@ static int fail(const char *fmt, ...)
     } while (0)
 
 extern "C" const char *asx_last_error(void) { return g_err.c_str(); }
-extern "C" int asx_abi_version(void) { return 1; }
+extern "C" int asx_abi_version(void) { return 2; }
 
 extern "C" int asx_device_count(void)
 {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
+}
+
+struct DevGuard {
+    int prev = -1;
+    bool ok = false;
+    explicit DevGuard(int dev)
+    {
+        if (hipGetDevice(&prev) == hipSuccess && hipSetDevice(dev) == hipSuccess) ok = true;
+    }
+    ~DevGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+extern "C" int asx_current_device(void)
+{
+    int d = -1;
+    if (hipGetDevice(&d) != hipSuccess) return -1;
+    return d;
 }
 
 // ---------------------------------------------------------------------------
@@ -132,6 +149,8 @@ static int plan_init(asx_plan *p, size_t N, size_t max_batch, const char *split)
     d.src_valid = h.src_valid;
     d.src_period = (uint32_t)(2 * N);
     d.nout = (uint32_t)(2 * N);
+    // the device's r is the unnormalised inverse transform: F times the plain sum of products
+    d.bound_scale = 2.0f * ASX_BOUND_C * 5.9604645e-8f * log2f((float)h.F) * (float)h.F;
     d.st1 = h.st1; d.st2 = h.st2;
     d.threads_cols = asx_pick_threads(h.st1, h.T / 2, 64, asx_lds_bytes_cols(d));
     d.threads_rows = asx_pick_threads(h.st2, 2, (h.M2 + ASX_ROW_STEPS - 1) / ASX_ROW_STEPS, asx_lds_bytes_rows(d));
@@ -155,14 +174,22 @@ static int plan_init(asx_plan *p, size_t N, size_t max_batch, const char *split)
     if (g > max_batch) g = max_batch;
     p->group = g;
     if (const char *e = getenv("ASX_LANES")) p->nlanes = atoi(e) == 2 ? 2 : 1;
+    // candidate capacity per pair of the peak refinement (asx_internal.h): all 2N lags for short
+    // tracks, else N/64 clamped to [ASX_CAND_MIN, ASX_CAND_MAX]
+    size_t cap = std::min<size_t>(std::max<size_t>(N / 64, ASX_CAND_MIN), ASX_CAND_MAX);
+    cap = std::min<size_t>(cap, 2 * N);
     for (int l = 0; l < p->nlanes; l++) {
         asx_plan::Lane &ln = p->lanes[l];
+        ln.pk.cap = (uint32_t)cap;
         if (dev_alloc(p, &ln.zxa, g * h.M) || dev_alloc(p, &ln.zya, g * h.M) || dev_alloc(p, &ln.ga, g * h.M) ||
-            dev_alloc(p, &ln.pk.partials, g * (size_t)h.ntiles) || dev_alloc(p, &ln.pk.cand_n, g * (size_t)h.ntiles) ||
-            dev_alloc(p, &ln.pk.cand, g * (size_t)h.ntiles * ASX_CAND_TILE) || dev_alloc(p, &ln.pk.refine_n, g) ||
-            dev_alloc(p, &ln.pk.refine_idx, g * ASX_CAND_PAIR) || dev_alloc(p, &ln.pk.refine_val, g * ASX_CAND_PAIR) ||
-            dev_alloc(p, &ln.seg, g) || dev_alloc(p, &ln.psums, g * ASX_PEARSON_BLOCKS * 5))
+            dev_alloc(p, &ln.pk.nrm_part, g * 2 * (size_t)h.ntiles) || dev_alloc(p, &ln.pk.bound2, g) ||
+            dev_alloc(p, &ln.pk.pairmax, g) || dev_alloc(p, &ln.pk.cand_n, g) ||
+            dev_alloc(p, &ln.pk.cand, g * cap) || dev_alloc(p, &ln.pk.refine_n, g) ||
+            dev_alloc(p, &ln.pk.refine_idx, g * cap) || dev_alloc(p, &ln.pk.refine_val, g * cap) ||
+            dev_alloc(p, &ln.pk.overflows, 1) ||
+            dev_alloc(p, &ln.seg, g) || dev_alloc(p, &ln.psums, g * ASX_PEARSON_BLOCKS * 6))
             return -1;
+        HIP_TRY(hipMemset(ln.pk.overflows, 0, sizeof(unsigned long long)));
         HIP_TRY(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&ln.done, hipEventDisableTiming));
     }
@@ -323,6 +350,44 @@ extern "C" long asx_plan_debug_stamps(asx_plan *p, unsigned long long *out, size
     return (long)n;
 }
 
+extern "C" int asx_plan_peak_overflows(asx_plan *p, uint64_t *count)
+{
+    if (!p || !count) return fail("asx_plan_peak_overflows: null argument");
+    std::lock_guard<std::mutex> guard(p->lock);
+    DevGuard dg(p->device);
+    if (!dg.ok) return fail("cannot select device %d", p->device);
+    unsigned long long total = 0;
+    for (int l = 0; l < p->nlanes; l++) {
+        unsigned long long v = 0;
+        HIP_TRY(hipStreamSynchronize(p->lanes[l].stream));
+        HIP_TRY(hipStreamSynchronize(p->stream));
+        HIP_TRY(hipMemcpy(&v, p->lanes[l].pk.overflows, sizeof(v), hipMemcpyDeviceToHost));
+        total += v;
+    }
+    *count = total;
+    return 0;
+}
+
+// diagnostic (not in the public header): the peak-search state of pair `pair` of the last group on lane 0
+extern "C" int asx_plan_debug_peak(asx_plan *p, size_t pair, float *bound2, uint32_t *cand_n, uint32_t *refine_n,
+                                   unsigned long long *pairmax, double *vals, uint32_t *idxs, size_t cap)
+{
+    if (!p || pair >= p->group) return -1;
+    DevGuard dg(p->device);
+    const AsxPeakWs &W = p->lanes[0].pk;
+    (void)hipDeviceSynchronize();
+    if (hipMemcpy(bound2, W.bound2 + pair, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    if (hipMemcpy(cand_n, W.cand_n + pair, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    if (hipMemcpy(refine_n, W.refine_n + pair, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    if (hipMemcpy(pairmax, W.pairmax + pair, 8, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    size_t n = std::min<size_t>(cap, W.cap);
+    if (vals && hipMemcpy(vals, W.refine_val + pair * (size_t)W.cap, n * 8, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    if (idxs && hipMemcpy(idxs, W.refine_idx + pair * (size_t)W.cap, n * 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return 0;
+}
+
+extern "C" size_t asx_plan_peak_capacity(const asx_plan *p) { return p ? p->lanes[0].pk.cap : 0; }
+
 extern "C" int asx_plan_threads(const asx_plan *p, int *cols, int *rows)
 {
     if (!p) return -1;
@@ -343,16 +408,6 @@ extern "C" int asx_plan_split(const asx_plan *p, int *m1, int *m2, int *tile_col
 // ---------------------------------------------------------------------------
 // running groups
 // ---------------------------------------------------------------------------
-struct DevGuard {
-    int prev = -1;
-    bool ok = false;
-    explicit DevGuard(int dev)
-    {
-        if (hipGetDevice(&prev) == hipSuccess && hipSetDevice(dev) == hipSuccess) ok = true;
-    }
-    ~DevGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
-};
-
 static int prof_mark(asx_plan *p, hipStream_t s, size_t slot)
 {
     if (!p->profiling) return 0;
@@ -375,9 +430,9 @@ static int run_group(asx_plan *p, const float *d_src, const float *d_smp, const 
     asx_plan::Lane &W = p->lanes[lane];
     const size_t e0 = group_index * 6;
     if (prof_mark(p, s, e0 + 0)) return -1;
-    asx_launch_fwd_cols(P, d_src, d_smp, W.zxa, W.zya, (int)g, s);
+    asx_launch_fwd_cols(P, d_src, d_smp, W.zxa, W.zya, W.pk, (int)g, s);
     if (prof_mark(p, s, e0 + 1)) return -1;
-    asx_launch_rows(P, W.zxa, W.zya, W.ga, (int)g, s);
+    asx_launch_rows(P, W.zxa, W.zya, W.ga, W.pk, (int)g, s);
     if (prof_mark(p, s, e0 + 2)) return -1;
     asx_launch_inv_cols(P, W.ga, W.pk, d_r, (int)g, s);
     if (prof_mark(p, s, e0 + 3)) return -1;
@@ -520,36 +575,52 @@ extern "C" int asx_xcorr_f64(asx_plan *p, const double *source, const double *sa
     return h_ret;
 }
 
+// pearson_coefficient() is called on its own by the reference's tests and may be called often: its
+// device buffers are kept per device and only ever grow (the reference allocates nothing here).
+struct PearsonScratch {
+    std::mutex lock;
+    size_t cap = 0;              // doubles per array
+    double *a = nullptr, *b = nullptr, *ps = nullptr, *c = nullptr;
+    AsxSeg *seg = nullptr;
+    hipStream_t stream = nullptr;
+};
+static PearsonScratch g_pearson[16];
+
 extern "C" int asx_pearson_f64(const double *a, const double *b, size_t n, int device, double *out)
 {
     if (!a || !b || !out) return fail("asx_pearson_f64: null argument");
     if (n > 0xFFFFFFFFull) return fail("asx_pearson_f64: range too long");
     if (asx_device_count() == 0) return fail("no usable HIP device; this library has no CPU fallback");
     if (device < 0) HIP_TRY(hipGetDevice(&device));
+    if (device >= 16) return fail("asx_pearson_f64: device %d not supported", device);
     DevGuard dg(device);
     if (!dg.ok) return fail("cannot select device %d", device);
-    double *d_a = nullptr, *d_b = nullptr, *d_ps = nullptr, *d_c = nullptr;
-    AsxSeg *d_seg = nullptr;
-    int rc = -1;
+    PearsonScratch &S = g_pearson[device];
+    std::lock_guard<std::mutex> guard(S.lock);
+    if (!S.stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
+        HIP_TRY(hipMalloc((void **)&S.ps, ASX_PEARSON_BLOCKS * 6 * sizeof(double)));
+        HIP_TRY(hipMalloc((void **)&S.c, sizeof(double)));
+        HIP_TRY(hipMalloc((void **)&S.seg, sizeof(AsxSeg)));
+    }
+    if (n > S.cap) {
+        (void)hipFree(S.a); (void)hipFree(S.b);
+        S.a = S.b = nullptr; S.cap = 0;
+        const size_t want = std::max<size_t>(n, 4096);
+        HIP_TRY(hipMalloc((void **)&S.a, want * sizeof(double)));
+        HIP_TRY(hipMalloc((void **)&S.b, want * sizeof(double)));
+        S.cap = want;
+    }
     AsxSeg seg{};
     seg.lag = 0; seg.src_off = 0; seg.smp_off = 0; seg.len = (uint32_t)n; seg.peak = 0;
-    do {
-        if (hipMalloc((void **)&d_a, (n ? n : 1) * sizeof(double)) != hipSuccess) break;
-        if (hipMalloc((void **)&d_b, (n ? n : 1) * sizeof(double)) != hipSuccess) break;
-        if (hipMalloc((void **)&d_ps, ASX_PEARSON_BLOCKS * 5 * sizeof(double)) != hipSuccess) break;
-        if (hipMalloc((void **)&d_c, sizeof(double)) != hipSuccess) break;
-        if (hipMalloc((void **)&d_seg, sizeof(AsxSeg)) != hipSuccess) break;
-        if (hipMemcpy(d_a, a, n * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) break;
-        if (hipMemcpy(d_b, b, n * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) break;
-        if (hipMemcpy(d_seg, &seg, sizeof(seg), hipMemcpyHostToDevice) != hipSuccess) break;
-        asx_launch_pearson_f64(d_a, d_b, 0, 0, (uint32_t)n, d_seg, d_ps, nullptr, d_c, nullptr, 1, nullptr);
-        if (hipGetLastError() != hipSuccess) break;
-        if (hipMemcpy(out, d_c, sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) break;
-        rc = 0;
-    } while (0);
-    if (rc != 0) fail("asx_pearson_f64: HIP failure: %s", hipGetErrorString(hipGetLastError()));
-    (void)hipFree(d_a); (void)hipFree(d_b); (void)hipFree(d_ps); (void)hipFree(d_c); (void)hipFree(d_seg);
-    return rc;
+    HIP_TRY(hipMemcpyAsync(S.a, a, n * sizeof(double), hipMemcpyHostToDevice, S.stream));
+    HIP_TRY(hipMemcpyAsync(S.b, b, n * sizeof(double), hipMemcpyHostToDevice, S.stream));
+    HIP_TRY(hipMemcpyAsync(S.seg, &seg, sizeof(seg), hipMemcpyHostToDevice, S.stream));
+    asx_launch_pearson_f64(S.a, S.b, 0, 0, (uint32_t)n, S.seg, S.ps, nullptr, S.c, nullptr, 1, S.stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, S.c, sizeof(double), hipMemcpyDeviceToHost, S.stream));
+    HIP_TRY(hipStreamSynchronize(S.stream));
+    return 0;
 }
 
 // ---------------------------------------------------------------------------

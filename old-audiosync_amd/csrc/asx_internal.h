@@ -21,13 +21,17 @@
 #define ASX_COL_LOADS 10                    // tile loads a thread keeps in flight in the column kernels
 #define ASX_ROW_STEPS 5                     // max ceil(M2 / blockDim) in k_rows (bins a thread owns in the load / combine / store phases)
 #define ASX_PEARSON_BLOCKS 64               // partial-sum blocks per pair
-// Peak refinement: every lag whose float32 |r| is within ASX_REFINE_EPS (relative) of the
-// float32 maximum is re-evaluated exactly (float64 dot product of the inputs) and the
-// reference's rule is applied to the exact values, so near-ties that float32 transforms
-// cannot resolve (e.g. the reference's own sin(i) test, margin 3e-8) come out as in float64.
-#define ASX_REFINE_EPS 1.0e-4f
-#define ASX_CAND_TILE 16                    // candidates kept per column tile
-#define ASX_CAND_PAIR 64                    // candidates re-evaluated per pair (more -> float32 result kept)
+// Peak refinement (src/cross_correlation.c:52-67 is a float64 scan).  The transforms run in float32, so
+// every float32 r[k] is off by at most B = ASX_BOUND_C * eps32 * log2(F) * |source|_2 * |sample|_2
+// (a worst-case bound of the three transforms is ~3 eps log2 F; measured maximum 0.4 eps log2 F).
+// Every lag whose float32 key is within 2B of the float32 maximum is re-evaluated EXACTLY (float64
+// dot product of the inputs, compensated summation) and the reference's rule is applied to the exact
+// values -- for any number of such lags up to the per-pair capacity below (pure tones at N = 1 440 000
+// have ~5 000).  The norms come for free from k_fwd_cols (it reads every input sample anyway).
+#define ASX_BOUND_C 4.0f
+#define ASX_CAND_MAX 16384                  // upper limit of a plan's per-pair candidate capacity
+#define ASX_CAND_MIN 2048
+#define ASX_DOT_BLOCKS 128                  // blocks per pair that walk the pair's candidate list
 
 // Radix schedule of one in-LDS transform of length n.
 // DIF stage i works on sub-blocks of length ns[i] = n / (radix[0]*...*radix[i-1]).
@@ -56,6 +60,7 @@ struct AsxDev {
     uint32_t src_valid;    // how many leading real samples of the (periodically extended) source are non-zero
     uint32_t src_period;   // 2N
     uint32_t nout;         // 2N: lags searched
+    float bound_scale;     // 2 * ASX_BOUND_C * eps32 * log2(F) * F: bound2 = bound_scale * |source|_2 * |sample|_2 (r is scaled by F)
     AsxStages st1, st2;    // schedules for length M1 and M2
     const float2 *tw1;     // w_{M1}^q, q < M1
     const float2 *tw2;     // w_{M2}^q, q < M2
@@ -84,10 +89,6 @@ struct AsxSeg {           // per pair, produced by k_finalize
 };
 
 // kernel launchers (defined in xcorr_kernels.hip, called from asx_api.hip)
-void asx_launch_fwd_cols(const AsxDev &P, const float *src, const float *smp, float2 *zxa,
-                         float2 *zya, int npairs, hipStream_t s);
-void asx_launch_rows(const AsxDev &P, const float2 *zxa, const float2 *zya, float2 *ga, int npairs,
-                     hipStream_t s);
 struct AsxCand {          // one near-maximum lag found by a column tile
     uint32_t idx;
     float key;
@@ -95,14 +96,22 @@ struct AsxCand {          // one near-maximum lag found by a column tile
 
 // per-group scratch of the peak search
 struct AsxPeakWs {
-    asx_peak_t *partials;  // [pairs][ntiles] tile maxima
-    uint32_t *cand_n;      // [pairs][ntiles] candidates seen by the tile (may exceed ASX_CAND_TILE)
-    AsxCand *cand;         // [pairs][ntiles][ASX_CAND_TILE]
-    uint32_t *refine_n;    // [pairs] lags to re-evaluate (0 = keep the float32 argmax)
-    uint32_t *refine_idx;  // [pairs][ASX_CAND_PAIR]
-    double *refine_val;    // [pairs][ASX_CAND_PAIR] exact r[idx]
+    float *nrm_part;       // [pairs][2][ntiles] sum of squares of the samples a k_fwd_cols block loaded
+    float *bound2;         // [pairs] 2B: width of the "as large as the maximum" window (k_rows, row 0)
+    asx_peak_t *pairmax;   // [pairs] running float32 maximum (atomicMax by the column tiles), zeroed by k_rows
+    uint32_t *cand_n;      // [pairs] candidates appended by the tiles (may exceed cap), zeroed by k_rows
+    AsxCand *cand;         // [pairs][cap]
+    uint32_t *refine_n;    // [pairs] lags to re-evaluate (0 = the float32 argmax stands)
+    uint32_t *refine_idx;  // [pairs][cap]
+    double *refine_val;    // [pairs][cap] exact r[idx]
+    unsigned long long *overflows; // [1] pairs whose candidate list did not fit (float32 argmax kept), cumulative
+    uint32_t cap;          // candidate capacity per pair
 };
 
+void asx_launch_fwd_cols(const AsxDev &P, const float *src, const float *smp, float2 *zxa,
+                         float2 *zya, const AsxPeakWs &W, int npairs, hipStream_t s);
+void asx_launch_rows(const AsxDev &P, const float2 *zxa, const float2 *zya, float2 *ga,
+                     const AsxPeakWs &W, int npairs, hipStream_t s);
 void asx_launch_inv_cols(const AsxDev &P, const float2 *ga, const AsxPeakWs &W, float *r_out,
                          int npairs, hipStream_t s);
 void asx_launch_finalize(const AsxDev &P, const AsxPeakWs &W, AsxSeg *seg, int npairs, hipStream_t s);

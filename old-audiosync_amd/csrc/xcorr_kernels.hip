@@ -73,6 +73,13 @@ __device__ __forceinline__ float2 tw_F(const AsxKP &P, uint32_t p)
     return cmul(lo, hi);
 }
 
+__device__ __forceinline__ float wave_sum_f32(float v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
 // ---------------------------------------------------------------------------
 // Column tiles.  A tile is T columns (T even, a power of two) of the [M1][M2] matrix,
 // held in LDS as [M1][T/2] float4 slots; a slot is two adjacent columns as they lie in HBM,
@@ -113,10 +120,12 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_fwd_cols(const AsxDe
                                                                       const float *__restrict__ src,
                                                                       const float *__restrict__ smp,
                                                                       float2 *__restrict__ zxa,
-                                                                      float2 *__restrict__ zya)
+                                                                      float2 *__restrict__ zya,
+                                                                      float *__restrict__ nrm_part)
 {
     const AsxDev &PD = *Pp; // the plan lives in device memory: uniform scalar loads, taken once
     const AsxKP P = asx_kp(PD);
+    __shared__ float nrm_red[ASX_FFT_THREADS_MAX / 64];
     const int tile = col_tile_of_block(blockIdx.x);
     if (tile >= P.ntiles) return; // grid.x is rounded up to a multiple of 16
     const bool is_smp = blockIdx.y != 0;
@@ -151,6 +160,9 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_fwd_cols(const AsxDe
     const uint32_t row_reals = 2u * (uint32_t)M2;                 // real samples per matrix row
     const bool fast = vec_in && (c0 + T <= M2) && (valid <= period) && (valid % row_reals == 0u);
     const int data_rows = fast ? (int)(valid / row_reals) : 0;     // rows below this are all data
+    // sum of squares of everything this block loads: |source|^2 and |sample|^2 (the scale of the
+    // float32 error bound of the peak search) come out of the pass that reads the inputs anyway
+    float ss = 0.f;
     for (int e0 = threadIdx.x; e0 < nelem4; e0 += ASX_COL_LOADS * nthreads) {
         float4 v[ASX_COL_LOADS];
         if (fast) {
@@ -185,10 +197,20 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_fwd_cols(const AsxDe
         }
         static_for<0, ASX_COL_LOADS>([&](auto I) __attribute__((always_inline)) {
             const int e = e0 + decltype(I)::value * nthreads;
-            if (e < nelem4) lds4[e] = v[I];
+            if (e < nelem4) {
+                lds4[e] = v[I];
+                ss = fmaf(v[I].x, v[I].x, fmaf(v[I].y, v[I].y, fmaf(v[I].z, v[I].z, fmaf(v[I].w, v[I].w, ss))));
+            }
         });
     }
+    ss = wave_sum_f32(ss);
+    if ((threadIdx.x & 63) == 0) nrm_red[threadIdx.x >> 6] = ss;
     __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = nrm_red[0];
+        for (int w = 1; w < (nthreads + 63) >> 6; w++) t += nrm_red[w];
+        nrm_part[(pair * 2 + blockIdx.y) * (size_t)P.ntiles + tile] = t;
+    }
     ASX_STAMP_AT(1, stamp_block, 1);
     if constexpr (STATIC) lds_fft_static<S1, false, true>(lds4, Lc, P.tw1, pre);
     else lds_fft<MAXR, false, true>(lds4, PD.st1, Lc, P.tw1, pre);
@@ -264,7 +286,7 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, ASX_ROWS_MIN_WAVES) void k_row
                                                                   const float2 *__restrict__ zya,
                                                                   float2 *__restrict__ ga,
                                                                   const int4 *__restrict__ row_tasks,
-                                                                  int M1, int M2_arg, uint32_t M)
+                                                                  int M1, int M2_arg, uint32_t M, AsxPeakWs W)
 {
     constexpr bool STATIC = !std::is_void<S2>::value;
     int M2 = M2_arg, nthreads = blockDim.x;
@@ -287,6 +309,20 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, ASX_ROWS_MIN_WAVES) void k_row
         const int pa = rt.x, pb = rt.y, k1 = rt.z, m1 = rt.w;
         const bool self = (k1 == m1);
         ASX_STAMP(0);
+        if (k1 == 0 && threadIdx.x < 64) {
+            // Row 0 of a pair also prepares the pair's peak search (k_inv_cols runs after this kernel):
+            // the float32 error bound from the norms k_fwd_cols left, and the running maximum and the
+            // candidate count back to zero.
+            const float *np = W.nrm_part + (size_t)pair * 2 * P.ntiles;
+            float sx = 0.f, sy = 0.f;
+            for (int t = threadIdx.x; t < P.ntiles; t += 64) { sx += np[t]; sy += np[P.ntiles + t]; }
+            sx = wave_sum_f32(sx); sy = wave_sum_f32(sy);
+            if (threadIdx.x == 0) {
+                W.bound2[pair] = PD.bound_scale * sqrtf(sx) * sqrtf(sy);
+                W.pairmax[pair] = 0;
+                W.cand_n[pair] = 0;
+            }
+        }
         LdsLayout Lf;
         Lf.ngroups = self ? 1 : 2; Lf.log_ngroups = 0;
         Lf.elem_stride = 1; Lf.group_stride = M2; Lf.nthreads = nthreads;
@@ -603,10 +639,26 @@ __device__ __forceinline__ float peak_key(asx_peak_t v)
     return __uint_as_float(b);
 }
 __device__ __forceinline__ uint32_t peak_index(asx_peak_t v) { return 0xFFFFFFFFu - (uint32_t)(v & 0xFFFFFFFFull); }
-// everything at or above this key is "as large as the maximum" for float32 transforms
-__device__ __forceinline__ float near_max_threshold(float kmax)
+// Everything at or above this key is "as large as the maximum" for float32 transforms: b2 = 2B,
+// B = the bound on |float32 r[k] - exact r[k]| (asx_internal.h).  If the exact maximum is at k*, then
+// key32(k*) >= exact(k*) - B >= exact(kmax32) - B >= key32(kmax32) - 2B.
+__device__ __forceinline__ float near_max_threshold(float kmax, float b2) { return kmax - b2; }
+
+// Append one near-maximum lag to the pair's candidate list (called from divergent code: the lanes of
+// the wave that are here together take ONE slot range with one atomic).
+__device__ __forceinline__ void cand_append(const AsxPeakWs &W, size_t pair, uint32_t idx, float key)
 {
-    return kmax > 0.f ? kmax * (1.0f - ASX_REFINE_EPS) : kmax;
+    const unsigned long long m = __ballot(1);
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)m) - 1;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(&W.cand_n[pair], (uint32_t)__popcll(m));
+    base = (uint32_t)__shfl((int)base, leader, 64);
+    const uint32_t slot = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    if (slot < W.cap) {
+        AsxCand c; c.idx = idx; c.key = key;
+        W.cand[pair * (size_t)W.cap + slot] = c;
+    }
 }
 
 template <int MAXR, class S1 = void, int TC = 0, int NT = 0>
@@ -616,9 +668,6 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_inv_cols(const AsxDe
     const AsxDev &PD = *Pp; // the plan lives in device memory: uniform scalar loads, taken once
     const AsxKP P = asx_kp(PD);
     __shared__ asx_peak_t red[ASX_FFT_THREADS_MAX / 64];
-    __shared__ asx_peak_t tile_best;
-    __shared__ uint32_t ncand;
-    __shared__ AsxCand lcand[ASX_CAND_TILE];
     const int tile = col_tile_of_block(blockIdx.x);
     if (tile >= P.ntiles) return; // grid.x is rounded up to a multiple of 16
     const size_t pair = blockIdx.y;
@@ -665,13 +714,18 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_inv_cols(const AsxDe
             if (e < nelem4) lds4[e] = v[I];
         });
     }
-    if (threadIdx.x == 0) ncand = 0;
     __syncthreads();
     ASX_STAMP_AT(2, stamp_block, 1);
     if constexpr (STATIC) lds_fft_static<S1, true, true>(lds4, Lc, P.tw1, pre);
     else lds_fft<MAXR, true, true>(lds4, PD.st1, Lc, P.tw1, pre);
     ASX_STAMP_AT(2, stamp_block, 2);
 
+    // The pair's running maximum so far (other tiles publish theirs with atomicMax below) and the width
+    // of the near-maximum window; both are consumed after the first pass of the scan.  ANY earlier value
+    // of the running maximum is a lower bound of the final one, so a stale read merely admits more
+    // candidates (k_finalize filters them against the final maximum).
+    const asx_peak_t run0 = W.pairmax[pair];
+    const float b2 = W.bound2[pair];
     // Peak search.  A thread meets its lags in increasing order, so a strict '>' keeps the
     // earliest of equal keys, like the reference's sequential scan (src/cross_correlation.c:60).
     // Fast path (block-uniform): the tile is full, every lag counts, lag 0 (the signed one) is
@@ -689,10 +743,7 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_inv_cols(const AsxDe
             const uint32_t idx = i0 + h;
             if (idx < P.nout && j2 + (h >> 1) < M2) {
                 const float key = peak_key_of(val[h], idx);
-                if (key >= thr) {
-                    const uint32_t slot = atomicAdd(&ncand, 1u);
-                    if (slot < ASX_CAND_TILE) { lcand[slot].idx = idx; lcand[slot].key = key; }
-                }
+                if (key >= thr) cand_append(W, pair, idx, key);
             }
         }
     };
@@ -730,11 +781,11 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_inv_cols(const AsxDe
         // every thread folds the wave entries itself: no second barrier to broadcast the result
         asx_peak_t tb = red[0];
         for (int w = 1; w < (int)((nthreads + 63) >> 6); w++) tb = peak_max(tb, red[w]);
-        if (threadIdx.x == 0) tile_best = tb;
-        // second look at the tile (still in LDS): lags as large as the tile maximum within float32
-        // accuracy.  Almost every thread is below the threshold; the one that holds the maximum
+        if (threadIdx.x == 0) atomicMax(&W.pairmax[pair], tb);
+        // second look at the tile (still in LDS): lags within the float32 error window of the largest
+        // key known so far.  Almost every thread is below the threshold; the one that holds the maximum
         // usually has no second slot near it and examines just that slot.
-        const float thr = near_max_threshold(peak_key(tb));
+        const float thr = near_max_threshold(peak_key(peak_max(tb, run0)), b2);
         if (best_m >= thr) {
             if (second_m >= thr) {
                 for (int e = threadIdx.x; e < nelem4; e += nthreads) {
@@ -770,20 +821,12 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_inv_cols(const AsxDe
         }
         best = best_idx == 0xFFFFFFFFu ? 0 : peak_pack_key(best_key, best_idx);
         best = block_peak_max(best, red);
-        if (threadIdx.x == 0) tile_best = best;
+        if (threadIdx.x == 0) { atomicMax(&W.pairmax[pair], best); red[0] = best; }
         __syncthreads();
-        // second look at the tile (still in LDS): lags as large as the tile maximum within
-        // float32 accuracy.  A lag near the GLOBAL maximum is necessarily near its tile's maximum.
-        const float thr = near_max_threshold(peak_key(tile_best));
+        // second look at the tile (still in LDS), as above
+        const float thr = near_max_threshold(peak_key(peak_max(red[0], run0)), b2);
         for (int e = threadIdx.x; e < nelem4; e += nthreads) examine_slot(e, lds4[e], thr);
     }
-    __syncthreads();
-    const size_t t = pair * (size_t)P.ntiles + tile;
-    if (threadIdx.x == 0) {
-        W.partials[t] = tile_best;
-        W.cand_n[t] = ncand;
-    }
-    if (threadIdx.x < ASX_CAND_TILE && threadIdx.x < ncand) W.cand[t * ASX_CAND_TILE + threadIdx.x] = lcand[threadIdx.x];
     ASX_STAMP_AT(2, stamp_block, 3);
 }
 
@@ -813,112 +856,189 @@ __device__ __forceinline__ AsxSeg make_seg(uint32_t peak, uint32_t N)
 
 __global__ __launch_bounds__(ASX_THREADS) void k_finalize(const AsxDev *__restrict__ Pp, AsxPeakWs W, AsxSeg *__restrict__ seg)
 {
-    const AsxDev &PD = *Pp; // the plan lives in device memory: uniform scalar loads, taken once
-    const AsxKP P = asx_kp(PD);
-    __shared__ asx_peak_t red[ASX_THREADS / 64];
-    __shared__ asx_peak_t pair_best;
-    __shared__ uint32_t nsel, overflow;
-    __shared__ uint32_t sel[ASX_CAND_PAIR];
+    const uint32_t N = Pp->N;
+    __shared__ uint32_t nsel;
     const size_t pair = blockIdx.x;
-    const asx_peak_t *partials = W.partials + pair * (size_t)P.ntiles;
-    asx_peak_t best = 0;
-    for (int t = threadIdx.x; t < P.ntiles; t += ASX_THREADS) best = peak_max(best, partials[t]);
-    best = block_peak_max(best, red);
-    if (threadIdx.x == 0) { pair_best = best; nsel = 0; overflow = 0; }
+    const asx_peak_t best = W.pairmax[pair];        // float32 maximum, smallest lag among equal keys
+    const uint32_t ntot = W.cand_n[pair];
+    const uint32_t n = ntot < W.cap ? ntot : W.cap;
+    // the tiles collected against the running maximum; keep what is near the FINAL maximum
+    const float thr = near_max_threshold(peak_key(best), W.bound2[pair]);
+    if (threadIdx.x == 0) nsel = 0;
     __syncthreads();
-
-    // gather the tiles' near-maximum lags that are also near the pair's maximum
-    const float thr = near_max_threshold(peak_key(pair_best));
-    for (int t = threadIdx.x; t < P.ntiles; t += ASX_THREADS) {
-        if (peak_key(partials[t]) < thr) continue;        // nothing in this tile can matter
-        const size_t tt = pair * (size_t)P.ntiles + t;
-        const uint32_t n = W.cand_n[tt];
-        if (n > ASX_CAND_TILE) atomicOr(&overflow, 1u);
-        for (uint32_t i = 0; i < n && i < ASX_CAND_TILE; i++) {
-            const AsxCand c = W.cand[tt * ASX_CAND_TILE + i];
-            if (c.key >= thr) {
-                const uint32_t slot = atomicAdd(&nsel, 1u);
-                if (slot < ASX_CAND_PAIR) sel[slot] = c.idx;
-            }
-        }
+    const AsxCand *c = W.cand + pair * (size_t)W.cap;
+    uint32_t *out = W.refine_idx + pair * (size_t)W.cap;
+    for (uint32_t i = threadIdx.x; i < n; i += ASX_THREADS) {
+        const AsxCand e = c[i];
+        if (e.key >= thr) out[atomicAdd(&nsel, 1u)] = e.idx;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        seg[pair] = make_seg(peak_index(pair_best), P.N);
-        // one candidate: the float32 argmax is unambiguous.  Too many (e.g. r == 0 everywhere):
-        // keep the float32 result, which already follows the smallest-index rule.
-        const bool refine = (nsel >= 2u && nsel <= ASX_CAND_PAIR && !overflow);
-        W.refine_n[pair] = refine ? nsel : 0u;
+        seg[pair] = make_seg(best ? peak_index(best) : 0u, N);
+        // One candidate: the float32 argmax is unambiguous.  More than the list holds (r == 0
+        // everywhere, or a signal periodic in more than `cap` lags): the float32 result stands, which
+        // already follows the smallest-index rule, and the event is counted (asx_plan_peak_overflows).
+        const bool over = ntot > W.cap;
+        W.refine_n[pair] = (!over && nsel >= 2u) ? nsel : 0u;
+        if (over) atomicAdd(W.overflows, 1ull);
     }
-    if (threadIdx.x < ASX_CAND_PAIR && threadIdx.x < nsel) W.refine_idx[pair * ASX_CAND_PAIR + threadIdx.x] = sel[threadIdx.x];
 }
 
 // ---------------------------------------------------------------------------
 // Exact re-evaluation of near-tied lags: r[k] = sum_{n<N} source[(n+k) mod 2N] * sample[n]
-// (the identity behind src/cross_correlation.c:232-239) in float64.
-// grid (ASX_CAND_PAIR, npairs); blocks beyond refine_n exit at once.
+// (the identity behind src/cross_correlation.c:232-239), accumulated as an
+// unevaluated sum of two doubles (error ~1e-30 relative: the products of float32 inputs are exact
+// in float64, those of float64 inputs carry their rounding error along via fma).
+// grid (ASX_DOT_BLOCKS, npairs): block x of a pair takes candidates x, x + gridDim.x, ...
 // ---------------------------------------------------------------------------
+struct dd_t {
+    double hi, lo;
+};
+__device__ __forceinline__ dd_t dd_add(dd_t a, dd_t b)
+{
+    const double s = a.hi + b.hi;
+    const double bb = s - a.hi;
+    double e = (a.hi - (s - bb)) + (b.hi - bb);
+    e += a.lo + b.lo;
+    dd_t r;
+    r.hi = s + e;
+    r.lo = e - (r.hi - s);
+    return r;
+}
 
 template <typename TIn>
 __global__ __launch_bounds__(ASX_THREADS) void k_refine_dots(const AsxDev *__restrict__ Pp, const TIn *__restrict__ src,
                                                               const TIn *__restrict__ smp, AsxPeakWs W)
 {
-    const AsxDev &PD = *Pp; // the plan lives in device memory: uniform scalar loads, taken once
-    const AsxKP P = asx_kp(PD);
-    __shared__ double red[ASX_THREADS / 64];
+    __shared__ double red[2][ASX_THREADS / 64];
     const size_t pair = blockIdx.y;
-    if (blockIdx.x >= W.refine_n[pair]) return;
-    const uint32_t k = W.refine_idx[pair * ASX_CAND_PAIR + blockIdx.x];
-    const uint32_t N = P.N, L = 2u * P.N;
+    const uint32_t ncand = W.refine_n[pair];
+    if (blockIdx.x >= ncand) return;
+    const uint32_t N = Pp->N, L = 2u * N;
     const TIn *x = src + pair * (size_t)L;
     const TIn *y = smp + pair * (size_t)N;
-    double acc = 0.0;
-    for (uint32_t n = threadIdx.x; n < N; n += ASX_THREADS) {
-        uint32_t i = n + k;
-        if (i >= L) i -= L;
-        acc += (double)x[i] * (double)y[n];
-    }
-    acc = wave_sum(acc);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) red[wave] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double t = red[0];
-        for (int w = 1; w < ASX_THREADS / 64; w++) t += red[w];
-        W.refine_val[pair * ASX_CAND_PAIR + blockIdx.x] = t;
+    for (uint32_t c = blockIdx.x; c < ncand; c += gridDim.x) {
+        const uint32_t k = W.refine_idx[pair * (size_t)W.cap + c];
+        double hi = 0.0, lo = 0.0;
+        for (uint32_t n = threadIdx.x; n < N; n += ASX_THREADS) {
+            uint32_t i = n + k;
+            if (i >= L) i -= L;
+            const double a = (double)x[i], b = (double)y[n];
+            const double p = a * b;
+            double pe = 0.0;
+            if (sizeof(TIn) == sizeof(double)) pe = fma(a, b, -p);
+            const double s = hi + p;
+            const double bb = s - hi;
+            lo += ((hi - (s - bb)) + (p - bb)) + pe;
+            hi = s;
+        }
+        dd_t acc;
+        acc.hi = hi; acc.lo = lo;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            dd_t o;
+            o.hi = __shfl_xor(acc.hi, off, 64);
+            o.lo = __shfl_xor(acc.lo, off, 64);
+            acc = dd_add(acc, o);
+        }
+        if (lane == 0) { red[0][wave] = acc.hi; red[1][wave] = acc.lo; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            dd_t t;
+            t.hi = red[0][0]; t.lo = red[1][0];
+            for (int w = 1; w < ASX_THREADS / 64; w++) {
+                dd_t o;
+                o.hi = red[0][w]; o.lo = red[1][w];
+                t = dd_add(t, o);
+            }
+            W.refine_val[pair * (size_t)W.cap + c] = t.hi + t.lo;
+        }
+        __syncthreads();
     }
 }
 
-// grid (npairs), one thread decides: the reference's max_abs_index rule on the exact values
-__global__ __launch_bounds__(64) void k_refine_pick(const AsxDev *__restrict__ Pp, AsxPeakWs W, AsxSeg *__restrict__ seg)
+// grid (npairs): the reference's max_abs_index rule (src/cross_correlation.c:52-67) on the exact values:
+// key(0) = r[0] signed, key(i) = |r[i]|, largest key, smallest lag among equal keys; a NaN key never
+// wins unless it sits at lag 0.
+__global__ __launch_bounds__(ASX_THREADS) void k_refine_pick(const AsxDev *__restrict__ Pp, AsxPeakWs W, AsxSeg *__restrict__ seg)
 {
-    const AsxDev &PD = *Pp; // the plan lives in device memory: uniform scalar loads, taken once
-    const AsxKP P = asx_kp(PD);
+    __shared__ double rkey[ASX_THREADS / 64];
+    __shared__ uint32_t ridx[ASX_THREADS / 64];
     const size_t pair = blockIdx.x;
     const uint32_t n = W.refine_n[pair];
-    if (n < 2u || threadIdx.x != 0) return;
-    double best_key = 0.0;
-    uint32_t best_idx = 0xFFFFFFFFu;
-    for (uint32_t i = 0; i < n; i++) {
-        const uint32_t idx = W.refine_idx[pair * ASX_CAND_PAIR + i];
-        const double v = W.refine_val[pair * ASX_CAND_PAIR + i];
+    if (n < 2u) return;
+    double bk = -INFINITY;
+    uint32_t bi = 0xFFFFFFFFu;
+    for (uint32_t i = threadIdx.x; i < n; i += ASX_THREADS) {
+        const uint32_t idx = W.refine_idx[pair * (size_t)W.cap + i];
+        const double v = W.refine_val[pair * (size_t)W.cap + i];
         double key;
-        if (idx == 0u) key = (v != v) ? INFINITY : v + 0.0;
-        else { key = fabs(v); if (key != key) key = -INFINITY; }
-        if (best_idx == 0xFFFFFFFFu || key > best_key || (key == best_key && idx < best_idx)) {
-            best_key = key;
-            best_idx = idx;
-        }
+        if (idx == 0u) key = (v != v) ? (double)INFINITY : v + 0.0;
+        else { key = fabs(v); if (key != key) key = -(double)INFINITY; }
+        if (key > bk || (key == bk && idx < bi)) { bk = key; bi = idx; }
     }
-    seg[pair] = make_seg(best_idx, P.N);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double ok = __shfl_xor(bk, off, 64);
+        const uint32_t oi = (uint32_t)__shfl_xor((int)bi, off, 64);
+        if (ok > bk || (ok == bk && oi < bi)) { bk = ok; bi = oi; }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { rkey[wave] = bk; ridx[wave] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < ASX_THREADS / 64; w++)
+            if (rkey[w] > bk || (rkey[w] == bk && ridx[w] < bi)) { bk = rkey[w]; bi = ridx[w]; }
+        if (bi != 0xFFFFFFFFu) seg[pair] = make_seg(bi, Pp->N);
+    }
 }
 
 // ---------------------------------------------------------------------------
-// Pearson coefficient (src/cross_correlation.c:74-116).  One streaming pass with
-// float64 accumulators: cov = Sxy - Sx*Sy/n, etc.  The reduction tree is fixed
-// (block-partition by index, wave butterflies), so identical segments give
-// bit-identical Sxx, Syy, Sxy and therefore exactly +-1.0.
+// Pearson coefficient (src/cross_correlation.c:74-116).  The reference makes two passes (means, then
+// the centred sums); here ONE streaming pass gives the same numbers: every thread accumulates its
+// elements relative to a pivot (its own first element), turns the five sums into
+// (count, mean, centred second moments) and the partitions are merged pairwise with the exact update
+// formulas (Chan et al.): no large-offset cancellation anywhere (offset 1e6, amplitude 0.1 is fine).
+// The merge tree is fixed, and x and y go through the same operations, so identical segments give
+// bit-identical Mxx, Myy, Cxy and therefore exactly +-1.0 (tests/test_cross_correlation.c:29).
 // ---------------------------------------------------------------------------
+struct PStat {
+    double n, mx, my, mxx, myy, cxy;
+};
+__device__ __forceinline__ PStat pstat_merge(const PStat A, const PStat B)
+{
+    if (B.n == 0.0) return A;
+    if (A.n == 0.0) return B;
+    const double n = A.n + B.n;
+    const double dx = B.mx - A.mx, dy = B.my - A.my;
+    const double fb = B.n / n, w = A.n * fb;
+    PStat R;
+    R.n = n;
+    R.mx = A.mx + dx * fb;
+    R.my = A.my + dy * fb;
+    R.mxx = (A.mxx + B.mxx) + (dx * dx) * w;
+    R.myy = (A.myy + B.myy) + (dy * dy) * w;
+    R.cxy = (A.cxy + B.cxy) + (dx * dy) * w;
+    return R;
+}
+__device__ __forceinline__ PStat pstat_wave_merge(PStat v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        PStat o;
+        o.n = __shfl_xor(v.n, off, 64);
+        o.mx = __shfl_xor(v.mx, off, 64);
+        o.my = __shfl_xor(v.my, off, 64);
+        o.mxx = __shfl_xor(v.mxx, off, 64);
+        o.myy = __shfl_xor(v.myy, off, 64);
+        o.cxy = __shfl_xor(v.cxy, off, 64);
+        // the lane with the lower index is always "A": both partners then compute the same merge
+        const bool lower = (threadIdx.x & off) == 0;
+        v = lower ? pstat_merge(v, o) : pstat_merge(o, v);
+    }
+    return v;
+}
 
 template <typename TIn>
 __global__ __launch_bounds__(ASX_THREADS) void k_pearson_partial(const TIn *__restrict__ src,
@@ -928,7 +1048,7 @@ __global__ __launch_bounds__(ASX_THREADS) void k_pearson_partial(const TIn *__re
                                                                   const AsxSeg *__restrict__ seg,
                                                                   double *__restrict__ psums)
 {
-    __shared__ double red[5][ASX_THREADS / 64];
+    __shared__ double red[6][ASX_THREADS / 64];
     const size_t pair = blockIdx.y;
     const AsxSeg s = seg[pair];
     const uint32_t chunk = (basis_len + ASX_PEARSON_BLOCKS - 1) / ASX_PEARSON_BLOCKS;
@@ -937,18 +1057,23 @@ __global__ __launch_bounds__(ASX_THREADS) void k_pearson_partial(const TIn *__re
     if (hi > s.len) hi = s.len;
     const TIn *x = src + pair * src_pitch + s.src_off;
     const TIn *y = smp + pair * smp_pitch + s.smp_off;
+    uint64_t i = lo + 4u * threadIdx.x;
+    double px = 0, py = 0; // pivots: the first element this thread meets
+    if (i < hi) { px = (double)x[i]; py = (double)y[i]; }
     double sx = 0, sy = 0, sxy = 0, sxx = 0, syy = 0;
+    uint32_t cnt = 0;
     auto add = [&](double a, double b) {
-        sx += a;
-        sy += b;
-        sxy += a * b;
-        sxx += a * a;
-        syy += b * b;
+        const double da = a - px, db = b - py;
+        sx += da;
+        sy += db;
+        sxy += da * db;
+        sxx += da * da;
+        syy += db * db;
+        cnt++;
     };
     // four consecutive elements per lane and step: 16-byte loads (the segments start at any element,
     // so the vector type only promises element alignment), then the few elements that are left
     typedef TIn vec4u __attribute__((ext_vector_type(4), aligned(sizeof(TIn))));
-    uint64_t i = lo + 4u * threadIdx.x;
     for (; i + 3 < hi; i += 4u * ASX_THREADS) {
         const vec4u a = *reinterpret_cast<const vec4u *>(x + i), b = *reinterpret_cast<const vec4u *>(y + i);
         add((double)a.x, (double)b.x);
@@ -957,15 +1082,32 @@ __global__ __launch_bounds__(ASX_THREADS) void k_pearson_partial(const TIn *__re
         add((double)a.w, (double)b.w);
     }
     for (; i < hi; i++) add((double)x[i], (double)y[i]); // only the lane that holds the ragged end
-    double v[5] = { wave_sum(sx), wave_sum(sy), wave_sum(sxy), wave_sum(sxx), wave_sum(syy) };
+    PStat v;
+    v.n = (double)cnt;
+    v.mx = v.my = v.mxx = v.myy = v.cxy = 0.0;
+    if (cnt) {
+        v.mx = px + sx / v.n;
+        v.my = py + sy / v.n;
+        v.mxx = sxx - sx * sx / v.n;
+        v.myy = syy - sy * sy / v.n;
+        v.cxy = sxy - sx * sy / v.n;
+    }
+    v = pstat_wave_merge(v);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0)
-        for (int q = 0; q < 5; q++) red[q][wave] = v[q];
+    if (lane == 0) {
+        red[0][wave] = v.n; red[1][wave] = v.mx; red[2][wave] = v.my;
+        red[3][wave] = v.mxx; red[4][wave] = v.myy; red[5][wave] = v.cxy;
+    }
     __syncthreads();
-    if (threadIdx.x < 5) {
-        double t = red[threadIdx.x][0];
-        for (int w = 1; w < ASX_THREADS / 64; w++) t += red[threadIdx.x][w];
-        psums[(pair * ASX_PEARSON_BLOCKS + blockIdx.x) * 5 + threadIdx.x] = t;
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < ASX_THREADS / 64; w++) {
+            PStat o;
+            o.n = red[0][w]; o.mx = red[1][w]; o.my = red[2][w];
+            o.mxx = red[3][w]; o.myy = red[4][w]; o.cxy = red[5][w];
+            v = pstat_merge(v, o);
+        }
+        double *out = psums + (pair * ASX_PEARSON_BLOCKS + blockIdx.x) * 6;
+        out[0] = v.n; out[1] = v.mx; out[2] = v.my; out[3] = v.mxx; out[4] = v.myy; out[5] = v.cxy;
     }
 }
 
@@ -977,16 +1119,14 @@ __global__ __launch_bounds__(64) void k_pearson_final(const AsxSeg *__restrict__
                                                        int32_t *__restrict__ ret)
 {
     const size_t pair = blockIdx.x;
-    const double *p = psums + (pair * ASX_PEARSON_BLOCKS + threadIdx.x) * 5;
-    const double sx = wave_sum(p[0]), sy = wave_sum(p[1]), sxy = wave_sum(p[2]);
-    const double sxx = wave_sum(p[3]), syy = wave_sum(p[4]);
+    const double *p = psums + (pair * ASX_PEARSON_BLOCKS + threadIdx.x) * 6;
+    PStat v;
+    v.n = p[0]; v.mx = p[1]; v.my = p[2]; v.mxx = p[3]; v.myy = p[4]; v.cxy = p[5];
+    v = pstat_wave_merge(v);
     if (threadIdx.x == 0) {
         const AsxSeg s = seg[pair];
-        const double n = (double)s.len;
-        const double cov = sxy - sx * sy / n;
-        const double vx = sxx - sx * sx / n;
-        const double vy = syy - sy * sy / n;
-        const double c = cov / sqrt(vx * vy);
+        // src/cross_correlation.c:115; an empty or constant segment gives 0/0 = NaN like the reference
+        const double c = v.cxy / sqrt(v.mxx * v.myy);
         if (lag) lag[pair] = s.lag;
         coef[pair] = c;
         // src/cross_correlation.c:276: NaN coefficient -> return -1 (outputs already written)
@@ -1145,12 +1285,12 @@ static bool generic_only()
     X(400, 16, 320, 10, 10, 8, 5) X(300, 16, 256, 10, 10, 6, 5)
 
 void asx_launch_fwd_cols(const AsxDev &P, const float *src, const float *smp, float2 *zxa,
-                         float2 *zya, int npairs, hipStream_t s)
+                         float2 *zya, const AsxPeakWs &W, int npairs, hipStream_t s)
 {
     dim3 grid((P.ntiles + 15) / 16 * 16, 2, npairs);
 #define ASX_LAUNCH(...) \
     do { allow_big_lds((const void *)k_fwd_cols<__VA_ARGS__>, asx_lds_bytes_cols(P)); \
-         hipLaunchKernelGGL((k_fwd_cols<__VA_ARGS__>), grid, dim3(P.threads_cols), asx_lds_bytes_cols(P), s, P.self_dev, src, smp, zxa, zya); } while (0)
+         hipLaunchKernelGGL((k_fwd_cols<__VA_ARGS__>), grid, dim3(P.threads_cols), asx_lds_bytes_cols(P), s, P.self_dev, src, smp, zxa, zya, W.nrm_part); } while (0)
 #define ASX_TRY_STATIC(m1, t, nt, maxr, ...) \
     if (!generic_only() && P.T == (t) && P.threads_cols == (nt) && schedule_is(P.st1, m1, { __VA_ARGS__ })) { ASX_LAUNCH(maxr, Sched<m1, __VA_ARGS__>, t, nt); return; }
     ASX_STATIC_COLS(ASX_TRY_STATIC)
@@ -1160,8 +1300,8 @@ void asx_launch_fwd_cols(const AsxDev &P, const float *src, const float *smp, fl
 #undef ASX_LAUNCH
 }
 
-void asx_launch_rows(const AsxDev &P, const float2 *zxa, const float2 *zya, float2 *ga, int npairs,
-                     hipStream_t s)
+void asx_launch_rows(const AsxDev &P, const float2 *zxa, const float2 *zya, float2 *ga,
+                     const AsxPeakWs &W, int npairs, hipStream_t s)
 {
     const int ntasks = (P.M1 / 2 + 1) * npairs;
     size_t lds = asx_lds_bytes_rows(P);
@@ -1170,7 +1310,7 @@ void asx_launch_rows(const AsxDev &P, const float2 *zxa, const float2 *zya, floa
 #define ASX_LAUNCH(...) \
     do { allow_big_lds((const void *)k_rows<__VA_ARGS__>, lds); \
          int grid = ntasks; /* one task (pair, k1) per block */ \
-         hipLaunchKernelGGL((k_rows<__VA_ARGS__>), dim3(grid), dim3(P.threads_rows), lds, s, P.self_dev, zxa, zya, ga, P.row_tasks, P.M1, P.M2, P.M); } while (0)
+         hipLaunchKernelGGL((k_rows<__VA_ARGS__>), dim3(grid), dim3(P.threads_rows), lds, s, P.self_dev, zxa, zya, ga, P.row_tasks, P.M1, P.M2, P.M, W); } while (0)
     const int mr = max_radix(P.st2);
     // row lengths of the production sample lengths (plan_math.cpp's tuned table): schedule compiled in
     if (!generic_only() && P.threads_rows == 256 && schedule_is(P.st2, 1200, { 12, 10, 10 })) ASX_LAUNCH(12, Sched<1200, 12, 10, 10>, 256);
@@ -1203,15 +1343,15 @@ void asx_launch_finalize(const AsxDev &P, const AsxPeakWs &W, AsxSeg *seg, int n
 void asx_launch_refine_f32(const AsxDev &P, const float *src, const float *smp, const AsxPeakWs &W,
                            AsxSeg *seg, int npairs, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_refine_dots<float>, dim3(ASX_CAND_PAIR, npairs), dim3(ASX_THREADS), 0, s, P.self_dev, src, smp, W);
-    hipLaunchKernelGGL(k_refine_pick, dim3(npairs), dim3(64), 0, s, P.self_dev, W, seg);
+    hipLaunchKernelGGL(k_refine_dots<float>, dim3(ASX_DOT_BLOCKS, npairs), dim3(ASX_THREADS), 0, s, P.self_dev, src, smp, W);
+    hipLaunchKernelGGL(k_refine_pick, dim3(npairs), dim3(ASX_THREADS), 0, s, P.self_dev, W, seg);
 }
 
 void asx_launch_refine_f64(const AsxDev &P, const double *src, const double *smp, const AsxPeakWs &W,
                            AsxSeg *seg, int npairs, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_refine_dots<double>, dim3(ASX_CAND_PAIR, npairs), dim3(ASX_THREADS), 0, s, P.self_dev, src, smp, W);
-    hipLaunchKernelGGL(k_refine_pick, dim3(npairs), dim3(64), 0, s, P.self_dev, W, seg);
+    hipLaunchKernelGGL(k_refine_dots<double>, dim3(ASX_DOT_BLOCKS, npairs), dim3(ASX_THREADS), 0, s, P.self_dev, src, smp, W);
+    hipLaunchKernelGGL(k_refine_pick, dim3(npairs), dim3(ASX_THREADS), 0, s, P.self_dev, W, seg);
 }
 
 void asx_launch_pearson_f32(const float *src, const float *smp, size_t src_pitch, size_t smp_pitch,

@@ -22,9 +22,16 @@
 
 #define PLAN_CACHE_SLOTS 8
 
+/* One cache entry.  `users` counts the callers that are inside asx_xcorr_f64 with this plan: an
+ * entry is only ever destroyed when nobody uses it, so a concurrent caller with a ninth length
+ * (or audiosync_release_plans) cannot free a plan under another thread.  A plan belongs to the HIP
+ * device that was current when it was built, so the device is part of the key. */
 struct cached_plan {
     size_t sample_len;
+    int device;
     asx_plan *plan;
+    unsigned users;
+    int doomed;            /* evicted or released while in use: destroyed by its last user */
     unsigned long last_use;
 };
 
@@ -34,42 +41,77 @@ static pthread_mutex_t cache_mutex = PTHREAD_MUTEX_INITIALIZER;
 static struct cached_plan cache[PLAN_CACHE_SLOTS];
 static unsigned long use_clock;
 
-static asx_plan *plan_for(size_t sample_len)
+/* Returns a pinned entry (users incremented) or NULL.  *transient is set when the cache was full of
+ * plans in use: the caller then owns a private plan and destroys it itself. */
+static struct cached_plan *plan_acquire(size_t sample_len, asx_plan **transient)
 {
-    asx_plan *found = NULL;
+    struct cached_plan *found = NULL;
+    const int device = asx_current_device();
+    *transient = NULL;
     pthread_mutex_lock(&cache_mutex);
-    int victim = 0;
+    int victim = -1;
     for (int i = 0; i < PLAN_CACHE_SLOTS; i++) {
-        if (cache[i].plan && cache[i].sample_len == sample_len) {
-            cache[i].last_use = ++use_clock;
-            found = cache[i].plan;
+        struct cached_plan *c = &cache[i];
+        if (c->plan && !c->doomed && c->sample_len == sample_len && c->device == device) {
+            found = c;
             break;
         }
-        if (!cache[i].plan) victim = i;
-        else if (cache[victim].plan && cache[i].last_use < cache[victim].last_use) victim = i;
+        if (c->plan && c->users > 0) continue;                /* pinned (doomed or not): not a victim */
+        if (victim < 0) victim = i;
+        else if (!c->plan && cache[victim].plan) victim = i;  /* prefer an empty slot */
+        else if (c->plan && cache[victim].plan && c->last_use < cache[victim].last_use) victim = i;
     }
     if (!found) {
-        asx_plan *fresh = asx_plan_create(sample_len, 1, -1);
-        if (fresh) {
-            if (cache[victim].plan) asx_plan_destroy(cache[victim].plan);
-            cache[victim].plan = fresh;
-            cache[victim].sample_len = sample_len;
-            cache[victim].last_use = ++use_clock;
-            found = fresh;
+        /* Building a plan (tables, HBM workspaces) under the cache lock keeps two first callers with
+         * the same length from building it twice; it happens once per length. */
+        asx_plan *fresh = asx_plan_create(sample_len, 1, device);
+        if (fresh && victim >= 0) {
+            struct cached_plan *c = &cache[victim];
+            if (c->plan) asx_plan_destroy(c->plan);           /* users == 0: nobody holds it */
+            c->plan = fresh;
+            c->sample_len = sample_len;
+            c->device = device;
+            c->users = 0;
+            c->doomed = 0;
+            found = c;
+        } else if (fresh) {
+            *transient = fresh;                               /* every slot is in use right now */
         }
+    }
+    if (found) {
+        found->users++;
+        found->last_use = ++use_clock;
     }
     pthread_mutex_unlock(&cache_mutex);
     return found;
 }
 
-/* Drops every cached plan (frees the HBM workspaces).  Safe to call any time no
- * cross_correlation() is in flight. */
+static void plan_release(struct cached_plan *c)
+{
+    asx_plan *dead = NULL;
+    pthread_mutex_lock(&cache_mutex);
+    if (--c->users == 0 && c->doomed) {
+        dead = c->plan;
+        c->plan = NULL;
+        c->doomed = 0;
+    }
+    pthread_mutex_unlock(&cache_mutex);
+    if (dead) asx_plan_destroy(dead);
+}
+
+/* Drops every cached plan (frees the HBM workspaces).  Safe at any time: a plan that is in use is
+ * destroyed by the call that is using it, when that call returns. */
 void audiosync_release_plans(void)
 {
     pthread_mutex_lock(&cache_mutex);
     for (int i = 0; i < PLAN_CACHE_SLOTS; i++) {
-        if (cache[i].plan) asx_plan_destroy(cache[i].plan);
-        cache[i].plan = NULL;
+        if (!cache[i].plan) continue;
+        if (cache[i].users > 0) {
+            cache[i].doomed = 1;
+        } else {
+            asx_plan_destroy(cache[i].plan);
+            cache[i].plan = NULL;
+        }
     }
     pthread_mutex_unlock(&cache_mutex);
 }
@@ -81,13 +123,17 @@ int cross_correlation(double *source, double *sample, const size_t sample_len, l
     DEBUG_ASSERT(lag); DEBUG_ASSERT(coefficient);
     DEBUG_ASSERT(sample_len > 0);
 
-    asx_plan *plan = plan_for(sample_len);
+    asx_plan *transient = NULL;
+    struct cached_plan *entry = plan_acquire(sample_len, &transient);
+    asx_plan *plan = entry ? entry->plan : transient;
     if (plan == NULL) {
         /* same class of failure as a failed fftw_alloc_* in the reference: -1, outputs untouched */
         fprintf(stderr, "audiosync: no GPU plan for %zu frames: %s\n", sample_len, asx_last_error());
         return -1;
     }
     const int ret = asx_xcorr_f64(plan, source, sample, lag, coefficient);
+    if (entry) plan_release(entry);
+    else asx_plan_destroy(transient);
     if (ret == 0) {
         LOG("%ld frames of delay with a confidence of %f", *lag, *coefficient);
     }

@@ -19,7 +19,7 @@ def declared_symbols(header):
 
 def test_build_and_load():
     mod = graft.build()
-    assert mod.abi_version() == 1
+    assert mod.abi_version() == 2
 
 
 def test_every_declared_symbol_is_exported():

@@ -1,0 +1,211 @@
+"""Exactness of the peak search and of the Pearson reduction.
+
+The reference scans float64 values (src/cross_correlation.c:52-67); the HIP path transforms in
+float32 and re-evaluates, exactly, every lag inside the float32 error window of the float32 maximum.
+Tonal / periodic inputs (the reference's own test style, tests/test_cross_correlation.c:83-113:
+sin(i)) put thousands of lags in that window at production sizes.  Lag must equal the oracle's
+whenever the oracle's answer is defined (peak margin > 1 + 1e-12)."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from util import asx, graft
+
+pytestmark = pytest.mark.gpu
+
+COEF_TOL = 1e-5      # north_star
+MARGIN_DEFINED = 1.0 + 1e-12
+
+
+@pytest.fixture(scope="module")
+def mod():
+    m = asx()
+    assert m.device_count() >= 1, "no MI355X visible"
+    return m
+
+
+@pytest.fixture(scope="module")
+def hostlib():
+    L = ctypes.CDLL(os.path.join(graft.PKG_DIR, "libaudiosync.so"))
+    dp = ctypes.POINTER(ctypes.c_double)
+    L.cross_correlation.restype = ctypes.c_int
+    L.cross_correlation.argtypes = [dp, dp, ctypes.c_size_t, ctypes.POINTER(ctypes.c_long), dp]
+    L.pearson_coefficient.restype = ctypes.c_double
+    L.pearson_coefficient.argtypes = [dp, dp, dp, dp]
+    return L
+
+
+def call_cross_correlation(L, source, sample):
+    s = np.ascontiguousarray(source, dtype=np.float64)
+    t = np.ascontiguousarray(sample, dtype=np.float64)
+    dp = ctypes.POINTER(ctypes.c_double)
+    lag = ctypes.c_long(-12345)
+    coef = ctypes.c_double(-7.0)
+    ret = L.cross_correlation(s.ctypes.data_as(dp), t.ctypes.data_as(dp), t.size, ctypes.byref(lag),
+                              ctypes.byref(coef))
+    return ret, lag.value, coef.value
+
+
+def tonal_pairs(n):
+    """float32 pairs in the style of the reference's tests (pure functions of the index)"""
+    i = np.arange(2 * n, dtype=np.float64)
+    rng = np.random.default_rng(n)
+    out = {}
+    out["sin(i) vs sin(i)"] = (np.sin(i), np.sin(i[:n]))                       # tests/test_cross_correlation.c:83-96
+    out["sin(i) vs -sin(i+1)"] = (np.sin(i), -np.sin(i[:n] + 1.0))             # :98-113 style (shift, sign)
+    out["two tones"] = (np.sin(0.31 * i) + 0.7 * np.sin(0.071 * i + 1.0),
+                        np.sin(0.31 * i[:n] + 0.4) + 0.7 * np.sin(0.071 * i[:n] + 1.3))
+    out["square wave"] = (np.sign(np.sin(0.0646 * i)), np.sign(np.sin(0.0646 * i[:n] + 0.5)))
+    out["tone + weak noise"] = (np.sin(0.05 * i) + 1e-3 * rng.normal(size=2 * n),
+                                np.sin(0.05 * i[:n] + 2.0) + 1e-3 * rng.normal(size=n))
+    out["slow chirp"] = (np.sin(1e-9 * i * i + 0.01 * i), np.sin(1e-9 * (i[:n] + 777) ** 2 + 0.01 * (i[:n] + 777)))
+    return {k: (a.astype(np.float32), b.astype(np.float32)) for k, (a, b) in out.items()}
+
+
+@pytest.mark.parametrize("n", [144000, 1440000])
+def test_tonal_inputs_match_the_float64_argmax(mod, hostlib, n):
+    """BASELINE config 1 as written: reference-test-style inputs at N = 144 000 (and the headline size),
+    through the batched float32 entry point and through cross_correlation(double*)."""
+    pairs = tonal_pairs(n)
+    names = list(pairs)
+    src = np.stack([pairs[k][0] for k in names])
+    smp = np.stack([pairs[k][1] for k in names])
+    with mod.Plan(n, len(names), 0) as plan:
+        lag, coef, ret = plan.xcorr_batch_f32(src, smp)
+        overflows = plan.peak_overflows()
+        cap = plan.peak_capacity
+    assert overflows == 0, (overflows, cap)
+    defined = 0
+    for b, name in enumerate(names):
+        o_ret, o_lag, o_coef, o_r, margin = oracle.cross_correlation(src[b], smp[b], want_results=True)
+        r2, l2, c2 = call_cross_correlation(hostlib, src[b], smp[b])
+        assert (int(ret[b]), int(lag[b])) == (r2, l2), (name, n)      # both entry points agree with each other
+        if margin <= MARGIN_DEFINED:
+            continue   # the float64 reference itself is within rounding of a tie: no defined answer
+        defined += 1
+        assert int(ret[b]) == o_ret, (name, n)
+        assert int(lag[b]) == o_lag, (name, n, int(lag[b]), o_lag, margin - 1.0)
+        if o_ret == 0:
+            assert abs(float(coef[b]) - o_coef) < COEF_TOL, (name, n, float(coef[b]), o_coef)
+            assert abs(c2 - o_coef) < COEF_TOL, (name, n, c2, o_coef)
+    assert defined >= 4, defined
+
+
+def test_sin_of_i_is_a_many_candidate_case(mod):
+    """the case VERDICT r1 demonstrated: float64 lag 104348, margin 8e-12, a float32 pipeline says 103993"""
+    n = 144000
+    src, smp = tonal_pairs(n)["sin(i) vs sin(i)"]
+    o_ret, o_lag, o_coef, o_r, margin = oracle.cross_correlation(src, smp, want_results=True)
+    assert o_lag == 104348 and 1.0 + 1e-12 < margin < 1.0 + 1e-10
+    with mod.Plan(n, 1, 0) as plan:
+        lag, coef, ret = plan.xcorr_batch_f32(src[None], smp[None])
+        assert plan.peak_overflows() == 0
+    assert (int(ret[0]), int(lag[0])) == (o_ret, o_lag)
+
+
+@pytest.mark.parametrize("n", [1000, 48000, 144000, 1440000])
+def test_float32_error_stays_inside_the_bound(mod, n):
+    """|float32 r[k] - float64 r[k]| <= B = 4 eps32 log2(F) |source| |sample| is what makes the candidate
+    window sufficient (csrc/asx_internal.h); measured here with a factor 2 to spare, on noise and on tones."""
+    import torch
+    cases = {"noise": oracle.synth_pair(77, 2, n, 1)[:2], "sin(i)": tonal_pairs(n)["sin(i) vs sin(i)"],
+             "two tones": tonal_pairs(n)["two tones"]}
+    with mod.Plan(n, 1, 0) as plan:
+        F = plan.fft_len
+        bound_rel = 4.0 * 2.0 ** -24 * np.log2(F)
+        for name, (src, smp) in cases.items():
+            o_ret, o_lag, o_coef, o_r, margin = oracle.cross_correlation(src, smp, want_results=True)
+            d_src = torch.from_numpy(src).cuda()
+            d_smp = torch.from_numpy(smp).cuda()
+            d_r = torch.zeros(2 * n, dtype=torch.float32, device="cuda")
+            d_lag = torch.zeros(1, dtype=torch.int64, device="cuda")
+            d_coef = torch.zeros(1, dtype=torch.float64, device="cuda")
+            d_ret = torch.zeros(1, dtype=torch.int32, device="cuda")
+            plan.debug_r_dev(d_src.data_ptr(), d_smp.data_ptr(), d_r.data_ptr(), d_lag.data_ptr(),
+                             d_coef.data_ptr(), d_ret.data_ptr())
+            plan.sync()
+            # device r is the unnormalised transform of length F; the oracle's is unnormalised of length 2N
+            r = d_r.cpu().numpy().astype(np.float64) / F
+            scale = np.linalg.norm(src.astype(np.float64)) * np.linalg.norm(smp.astype(np.float64))
+            err = np.abs(r - o_r / (2.0 * n)).max() / scale
+            print("N=%d %-10s max |r32 - r64| / (|x||y|) = %.3g  (bound %.3g, ratio %.3f)" % (n, name, err, bound_rel, err / bound_rel))
+            assert err < 0.5 * bound_rel, (n, name, err, bound_rel)
+
+
+def test_overflow_is_counted_and_keeps_the_float32_rule(mod):
+    n = 48000
+    with mod.Plan(n, 2, 0) as plan:
+        cap = plan.peak_capacity
+        assert cap < 2 * n
+        # an all-zero sample: r == 0 at every lag, all 2N lags tie -> more than the list holds
+        src, _, _ = oracle.synth_pair(3, 3, n, 1)
+        zero = np.zeros(n, dtype=np.float32)
+        # a source periodic in 8 frames: 2N/8 exactly tied peaks
+        base = np.array([3, -1, 2, 0, -2, 1, -3, 0], dtype=np.float32)
+        per = np.tile(base, 2 * n // 8)
+        lag, coef, ret = plan.xcorr_batch_f32(np.stack([src, per]), np.stack([zero, per[:n]]))
+        assert plan.peak_overflows() == 2
+    assert int(ret[0]) == -1 and int(lag[0]) == 0          # like the reference: index 0, NaN coefficient
+    assert int(ret[1]) == 0 and int(lag[1]) % 8 == 0 and coef[1] == 1.0
+
+
+def test_many_ties_below_capacity_are_all_resolved(mod):
+    """a source periodic in 64 frames at N = 4096: 128 exactly tied peaks (more than round 1's limit of
+    64); all are re-evaluated, the exact values tie, the smallest lag wins like in the sequential scan"""
+    n = 4096
+    base = np.random.default_rng(5).integers(-4, 5, 64).astype(np.float32)
+    src = np.tile(base, 2 * n // 64)
+    with mod.Plan(n, 1, 0) as plan:
+        lag, coef, ret = plan.xcorr_batch_f32(src[None], src[None, :n])
+        assert plan.peak_overflows() == 0
+    assert (int(ret[0]), int(lag[0])) == (0, 0) and coef[0] == 1.0
+
+
+# ---- Pearson with large offsets (the reference is two-pass, src/cross_correlation.c:82-115) ----------
+
+def test_pearson_large_offsets_direct(hostlib):
+    rng = np.random.default_rng(99)
+    dp = ctypes.POINTER(ctypes.c_double)
+    worst = 0.0
+    for trial in range(40):
+        n = int(rng.choice([7, 1000, 4096, 144000, 300001]))
+        off_a, off_b = 10.0 ** rng.uniform(3, 7, 2) * rng.choice([-1, 1], 2)
+        amp_a, amp_b = 10.0 ** rng.uniform(-2, 0, 2)
+        base = rng.normal(size=n)
+        a = off_a + amp_a * base
+        b = off_b + amp_b * (rng.uniform(-1, 1) * base + rng.uniform(0.05, 1) * rng.normal(size=n))
+        if trial % 5 == 0:
+            a[0] = 50 * off_a          # an outlier as the very first element (the pivot of the first thread)
+        want = oracle.pearson_coefficient(a, b)
+        pa, pb = a.ctypes.data_as(dp), b.ctypes.data_as(dp)
+        ea = ctypes.cast(a.ctypes.data + 8 * n, dp)
+        eb = ctypes.cast(b.ctypes.data + 8 * n, dp)
+        got = hostlib.pearson_coefficient(pa, ea, pb, eb)
+        worst = max(worst, abs(got - want))
+        assert abs(got - want) < COEF_TOL, (trial, n, off_a, off_b, amp_a, amp_b, got, want)
+    print("pearson large offsets: worst |delta| = %.3g" % worst)
+
+
+def test_pearson_large_source_offset_through_cross_correlation(hostlib):
+    """cross_correlation(double*) runs the Pearson reduction on the caller's doubles.  The source carries a
+    DC offset of 1e3..3e4 x its amplitude, the sample none (a DC term in BOTH tracks swamps float32 transforms
+    and is outside what the path resolves -- see DESIGN.md); lag and coefficient must match the oracle."""
+    rng = np.random.default_rng(7)
+    for trial in range(8):
+        n = int(rng.choice([6000, 48000, 144000]))
+        amp = 10.0 ** rng.uniform(-2, 0)
+        off = amp * 10.0 ** rng.uniform(3, 4.5) * rng.choice([-1, 1])
+        d = int(rng.integers(-n // 2, n // 2))
+        x = rng.normal(size=3 * n)
+        src = off + amp * x[n: 3 * n]
+        smp = 0.5 * x[n + d: 2 * n + d] + 0.3 * rng.normal(size=n)
+        smp -= smp.mean()
+        src32, smp32 = src.astype(np.float32).astype(np.float64), smp.astype(np.float32).astype(np.float64)
+        o_ret, o_lag, o_coef, o_r, margin = oracle.cross_correlation(src32, smp32, want_results=True)
+        ret, lag, coef = call_cross_correlation(hostlib, src32, smp32)
+        assert margin > 1.0 + 1e-9
+        assert (ret, lag) == (o_ret, o_lag) == (0, d), (trial, n, off, amp, lag, o_lag, d)
+        assert abs(coef - o_coef) < COEF_TOL, (trial, n, off, amp, coef, o_coef)
