@@ -3,21 +3,35 @@
 
   python bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the hot path (asx_xcorr_batch_f32_dev: rfft, rfft,
-conj-multiply, irfft, |.|-argmax, Pearson) over one batch of synthetic 48 kHz
-mono float32 pairs already resident in HBM.  N=1 workload: BASELINE.json's
-headline, N = 1 440 000 frames per sample.  With N>1 ranks (torchrun, one
-process per GPU) the pairs are sharded over ranks, no data-path collective;
-RCCL only gathers the 20-byte results (weak scaling: per-GPU batch fixed).
+One "step" = one pass of the hot path (asx_xcorr_batch_f32_dev: rfft, rfft, conj-multiply, irfft,
+|.|-argmax with exact re-evaluation of near-ties, Pearson) over one batch of synthetic 48 kHz mono
+float32 pairs already resident in HBM.
 
-Prints ONE JSON line on rank 0 (contract in the task statement), carrying
-`roofline` (algorithmic bytes 52*N per pair, SURVEY.md 8d, over the measured
-time of the dominant kernel) and `cpu_baseline` (the oracle port timed on the
-host cores on a bounded sample).
+Workloads
+  headline  (the JSON line's `value`)  BASELINE.json's metric: N = 1 440 000 frames per sample, one
+            launch group of pairs per GPU per step.  With N>1 ranks the per-GPU batch is fixed
+            (`"scaling": "weak"`): pairs are independent, there is no data-path collective, RCCL only
+            all-gathers the 20 result bytes per pair, inside the timed region.
+  config4   (the JSON line's `config4` object)  BASELINE.json configs[3] as written: a FIXED batch of
+            8192 pairs, N = 480 000, block-partitioned over the ranks (strong scaling), inputs
+            generated on the device per shard, the same gather.
+
+Ranks: `--gpus N` with N > 1 and no WORLD_SIZE in the environment starts N ranks itself
+(`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`, one process per GPU)
+as a CHILD process before anything touches the GPU, and exits with the child's code; under torchrun
+(WORLD_SIZE set) it is a rank.  `--dry-run` walks the same rank / shard / gather code with the gloo
+backend and fabricated results (no GPU): the CPU test of the N>1 path.
+
+Rank 0 prints ONE JSON line carrying `roofline` (algorithmic bytes 52*N per pair, SURVEY.md 8d, over
+the live HIP-event duration of the dominant kernel) and `cpu_baseline` (the reference's cost model on
+the host cores: FFTW3 if the node has it, else the oracle's own DFT -- labelled).
 """
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -26,40 +40,74 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 BYTES_PER_FRAME = 52             # A(N) = 52*N bytes per cross-correlation
+ALGO_SHARE = {"fwd_cols": 28, "rows": 16, "inv_cols": 0, "pearson": 8}   # DESIGN.md "Algorithmic bytes"
+FAMILIES = ("fwd_cols", "rows", "inv_cols", "finalize", "pearson", "total")
+CONFIG4_BATCH, CONFIG4_N = 8192, 480000
+SEED = 20260101
+
+
+# --------------------------------------------------------------------------------------------------
+# CPU baseline (rank 0, N=1 only)
+# --------------------------------------------------------------------------------------------------
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def cpu_baseline(sample_len, seconds_budget=20.0):
-    """the oracle (C restatement of the reference, float64) on this host's cores,
-    one worker per core over distinct pairs; bounded sample."""
-    import numpy as np
+    """The reference's CPU path on this node's host cores (oracle/cpu_baseline.c): (i) faithful single-call
+    latency -- two threads for the forward transforms, plans and allocations per call, the cost model of
+    src/cross_correlation.c:33-36,159-239; (ii) node throughput -- one independent single-threaded worker per
+    core over distinct pairs.  Backend: FFTW3 if libfftw3.so.3 can be dlopen()ed here, else the oracle's DFT."""
     from concurrent.futures import ThreadPoolExecutor
     import oracle
     cores = os.cpu_count() or 1
-    workers = min(cores, 16)
-    pairs = [oracle.synth_pair(1, p, sample_len, 1) for p in range(workers)]
-    oracle.cross_correlation(pairs[0][0][: 2 * 4800], pairs[0][1][:4800])  # load the library
-    t0 = time.perf_counter()
-    oracle.cross_correlation(pairs[0][0], pairs[0][1])
-    one = time.perf_counter() - t0
-    rounds = max(1, int(seconds_budget / max(one, 1e-3) / 1.5))
-    rounds = min(rounds, 4)
+    backend = oracle.baseline_backend()
+    workers = min(cores, 256)
+    distinct = min(workers, 16)
+    pairs = [oracle.synth_pair(1, p, sample_len, 1) for p in range(distinct)]
+    pairs = [(s.astype("float64"), t.astype("float64")) for s, t, _ in pairs]
+    oracle.cross_correlation_faithful(pairs[0][0][: 2 * 4800], pairs[0][1][:4800])  # load the library
+    lat = []
+    for i in range(3):
+        t0 = time.perf_counter()
+        oracle.cross_correlation_faithful(*pairs[i % distinct])
+        lat.append(time.perf_counter() - t0)
+    one = statistics.median(lat)
+    rounds = max(1, min(4, int(seconds_budget / max(2.0 * one, 1e-3))))
 
     def work(i):
+        s, t = pairs[i % distinct]
         for _ in range(rounds):
-            oracle.cross_correlation(pairs[i][0], pairs[i][1])
+            oracle.cross_correlation_faithful(s, t) if workers == 1 else oracle.cross_correlation(s, t)
         return rounds
 
     t0 = time.perf_counter()
     with ThreadPoolExecutor(workers) as ex:
         done = sum(ex.map(work, range(workers)))
     dt = time.perf_counter() - t0
-    return {"value": done / dt, "unit": "cross-correlations/s", "cores": workers, "kind": "port",
-            "sample": "%d pairs of N=%d float32 (widened to float64), oracle/xcorr_oracle.c, "
-                      "%d threads, single-pair latency %.3f s" % (done, sample_len, workers, one)}
+    return {"value": done / dt, "unit": "cross-correlations/s", "cores": workers,
+            "kind": "reference" if backend == "fftw3" else "port", "backend": backend,
+            "nproc": cores, "cpu_model": cpu_model(),
+            "single_call_latency_s": one,
+            "single_call_model": "2 threads for the forward transforms, plan + 4 allocations per call "
+                                 "(src/cross_correlation.c:33-36,159-239)",
+            "sample": "%d calls of N=%d (float32 values widened to float64) on %d workers = all %d logical cores, "
+                      "%d distinct pairs, %.1f s; backend %s" % (done, sample_len, workers, cores, distinct, dt,
+                                                                 "FFTW3 (dlopen libfftw3.so.3)" if backend == "fftw3"
+                                                                 else "oracle/fft64.c (no libfftw3 on this node)")}
 
 
+# --------------------------------------------------------------------------------------------------
+# BASELINE configs 2 and 5 on one GPU (not the driver's contract line, same JSON style)
+# --------------------------------------------------------------------------------------------------
 def side_mode(args):
-    """BASELINE configs 2 and 5 on one GPU; not the driver's contract line, same JSON style."""
     import numpy as np
     import torch
     import __graft_entry__ as graft
@@ -68,7 +116,7 @@ def side_mode(args):
     torch.cuda.set_device(0)
     sr = 48000
     n_max = 30 * sr
-    src32, smp32, true_lag = oracle.synth_pair(20260101, 0, n_max, 1)
+    src32, smp32, true_lag = oracle.synth_pair(SEED, 0, n_max, 1)
     if args.mode == "streaming":
         # a delay every prefix can see (the generator's is up to +-0.75*N of the 30 s window)
         true_lag = 12345
@@ -101,49 +149,216 @@ def side_mode(args):
                     "ms_per_interval": {str(k): v * 1e3 for k, v in per.items()},
                     "config": {"workload": "streaming 3/6/10/15/20/30 s prefixes of one 30 s pair, f64 host buffers"}})
     else:
-        n = args.sample_len
-        plan = asx.Plan(n, 1, 0, split=args.split)
-        d_src = torch.from_numpy(src32[: 2 * n]).cuda(); d_smp = torch.from_numpy(smp32[:n]).cuda()
-        d_lag = torch.zeros(1, dtype=torch.int64, device="cuda"); d_coef = torch.zeros(1, dtype=torch.float64, device="cuda")
-        d_ret = torch.zeros(1, dtype=torch.int32, device="cuda")
-        stream = torch.cuda.current_stream().cuda_stream
-        def resident():
-            plan.xcorr_batch_dev(d_src.data_ptr(), d_smp.data_ptr(), 1, d_lag.data_ptr(), d_coef.data_ptr(), d_ret.data_ptr(), stream)
-            torch.cuda.synchronize()
-        def dropin():
-            return plan.xcorr_f64(src[: 2 * n], smp[:n])
-        for f in (resident, dropin):
-            for _ in range(3): f()
-        reps = max(5, args.steps)
-        t0 = time.perf_counter()
-        for _ in range(reps): resident()
-        t_res = (time.perf_counter() - t0) / reps
-        t0 = time.perf_counter()
-        for _ in range(reps): dropin()
-        t_abi = (time.perf_counter() - t0) / reps
-        out.update({"metric": "single pair latency N=%d" % n, "value": t_res * 1e3, "unit": "ms", "higher_is_better": False,
-                    "resident_float32_ms": t_res * 1e3, "double_abi_incl_h2d_ms": t_abi * 1e3,
-                    "config": {"workload": "one pair, N=%d; resident float32 vs cross_correlation(double*) incl. PCIe" % n}})
+        out.update(single_pair_latency(asx, torch, src32, smp32, args.sample_len, max(5, args.steps), args.split))
     print(json.dumps(out), flush=True)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--sample-len", type=int, default=1440000)
-    ap.add_argument("--batch", type=int, default=0, help="pairs per GPU per step (0 = auto)")
-    ap.add_argument("--noise-shift", type=int, default=1)
-    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--split", default=None)
-    ap.add_argument("--mode", default="batched", choices=["batched", "streaming", "single"],
-                    help="batched = the headline workload (default); streaming = BASELINE config 5 "
-                         "(growing window 3..30 s, plan reuse); single = config 2 (one pair, latency)")
-    args = ap.parse_args()
-    if args.mode != "batched":
-        return side_mode(args)
+def single_pair_latency(asx, torch, src32, smp32, n, reps, split=None):
+    """BASELINE config 2: one pair, resident float32 and through cross_correlation(double*) incl. the PCIe copy"""
+    import numpy as np
+    plan = asx.Plan(n, 1, torch.cuda.current_device(), split=split)
+    src, smp = src32[: 2 * n].astype(np.float64), smp32[:n].astype(np.float64)
+    d_src = torch.from_numpy(src32[: 2 * n]).cuda(); d_smp = torch.from_numpy(smp32[:n]).cuda()
+    d_lag = torch.zeros(1, dtype=torch.int64, device="cuda"); d_coef = torch.zeros(1, dtype=torch.float64, device="cuda")
+    d_ret = torch.zeros(1, dtype=torch.int32, device="cuda")
 
+    def resident():
+        plan.xcorr_batch_dev(d_src.data_ptr(), d_smp.data_ptr(), 1, d_lag.data_ptr(), d_coef.data_ptr(), d_ret.data_ptr(), 0)
+        plan.sync()
+
+    def dropin():
+        return plan.xcorr_f64(src, smp)
+
+    for f in (resident, dropin):
+        for _ in range(3):
+            f()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        resident()
+    t_res = (time.perf_counter() - t0) / reps
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        dropin()
+    t_abi = (time.perf_counter() - t0) / reps
+    plan.close()
+    return {"metric": "single pair latency N=%d" % n, "value": t_res * 1e3, "unit": "ms", "higher_is_better": False,
+            "resident_float32_ms": t_res * 1e3, "double_abi_incl_h2d_ms": t_abi * 1e3,
+            "config": {"workload": "one pair, N=%d; resident float32 vs cross_correlation(double*) incl. PCIe" % n}}
+
+
+# --------------------------------------------------------------------------------------------------
+# ranks
+# --------------------------------------------------------------------------------------------------
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(args, argv):
+    """N ranks as a child `python -m torch.distributed.run`; this process never touches the GPU."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus,
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(args):
+    """the rank / shard / gather code path on CPU (gloo), with fabricated results"""
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as graft
+    graft.load()
+    from audiosync_amd import sharding
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(free_port()))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if os.environ.get("ASX_BENCH_DRYRUN_FAIL") == "1" and rank == world - 1:
+        raise RuntimeError("injected rank failure (tests/test_bench_cli.py)")
+    ok = True
+    report = {}
+    for name, total in (("headline", 6 * world), ("config4", CONFIG4_BATCH)):
+        start, count = sharding.shard_range(total, rank, world)
+        width = (total + world - 1) // world
+        buf, (lag, coef, ret) = sharding.result_buffer(width, "cpu")
+        ids = torch.arange(start, start + count)
+        lag[:count] = 3 * ids - 7
+        coef[:count] = ids.double() / total
+        ret[:count] = -(ids % 2).int()
+        out, views = sharding.gather_result_buffers(buf, width)
+        for r in range(world):
+            s_r, c_r = sharding.shard_range(total, r, world)
+            want = torch.arange(s_r, s_r + c_r)
+            ok = ok and bool(torch.equal(views[r][0][:c_r], 3 * want - 7)) and bool(torch.equal(views[r][2][:c_r], -(want % 2).int()))
+        report[name] = {"total": total, "shard": [start, count]}
+    t = torch.tensor([1.0 if ok else 0.0])
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "world_size_seen": dist.get_world_size(), "backend": "gloo",
+                          "results_ok": bool(t.item() == 1.0), "shards_rank0": report}), flush=True)
+    dist.destroy_process_group()
+    return 0 if t.item() == 1.0 else 1
+
+
+class Workload:
+    """`count` pairs of sample_len frames on this rank (pair ids first_pair ...), results gathered over ranks"""
+
+    def __init__(self, asx, sharding, torch, dist, dev, stream, n, total, world, rank, multi, noise_shift, split):
+        self.torch, self.dist, self.sharding, self.multi, self.world, self.rank = torch, dist, sharding, multi, world, rank
+        self.n, self.total = n, total
+        self.start, self.count = sharding.shard_range(total, rank, world)
+        self.width = (total + world - 1) // world          # every rank's result buffer holds `width` pairs
+        self.stream = stream
+        self.sh = stream.cuda_stream
+        assert self.sh != 0, "an explicit (non-null) stream is handed to the library and to the collective"
+        c = max(self.count, 1)
+        self.d_src = torch.empty(c * 2 * n, dtype=torch.float32, device=dev)
+        self.d_smp = torch.empty(c * n, dtype=torch.float32, device=dev)
+        self.d_true = torch.full((self.width,), -1, dtype=torch.int64, device=dev)
+        self.res_buf, (self.d_lag, self.d_coef, self.d_ret) = sharding.result_buffer(self.width, dev)
+        self.gather_out = torch.empty((world, sharding.result_bytes(self.width)), dtype=torch.uint8, device=dev) if multi else None
+        self.true_out = torch.empty((world, self.width), dtype=torch.int64, device=dev) if multi else None
+        self.gathered = None
+        if self.count:
+            asx.synth_pairs_dev(SEED, self.start, self.count, n, noise_shift, self.d_src.data_ptr(),
+                                self.d_smp.data_ptr(), self.d_true.data_ptr(), self.sh)
+        self.plan = asx.Plan(n, c, torch.cuda.current_device(), split=split)
+
+    def step(self):
+        if self.count:
+            self.plan.xcorr_batch_dev(self.d_src.data_ptr(), self.d_smp.data_ptr(), self.count, self.d_lag.data_ptr(),
+                                      self.d_coef.data_ptr(), self.d_ret.data_ptr(), self.sh)
+        if self.multi:
+            # the only exchange on this path: RCCL all-gather of the 20 result bytes per pair of every shard,
+            # on the same explicit stream, behind the kernels that produce them
+            self.gathered = self.sharding.gather_result_buffers(self.res_buf, self.width, out=self.gather_out)
+
+    def timed(self, steps, warmup):
+        torch, dist = self.torch, self.dist
+        for _ in range(warmup):
+            self.step()
+        torch.cuda.synchronize()
+        if self.multi:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step()
+        torch.cuda.synchronize()
+        if self.multi:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if self.multi:
+            t = torch.tensor([dt], dtype=torch.float64, device=self.d_lag.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    def verify(self):
+        """one more step into cleared buffers; every rank's slice of what the gather delivered must equal that
+        rank's planted delays (gathered separately), ret all zero"""
+        torch, dist = self.torch, self.dist
+        self.res_buf.zero_()
+        if self.multi:
+            self.gather_out.zero_()
+        self.step()
+        torch.cuda.synchronize()
+        ok = bool(torch.equal(self.d_lag[: self.count], self.d_true[: self.count])) and int(self.d_ret[: self.count].abs().sum()) == 0
+        if self.multi:
+            dist.all_gather_into_tensor(self.true_out.view(-1), self.d_true)
+            torch.cuda.synchronize()
+            views = self.gathered[1]
+            ok = ok and len(views) == self.world
+            for r in range(self.world):
+                c_r = self.sharding.shard_range(self.total, r, self.world)[1]
+                ok = ok and bool(torch.equal(views[r][0][:c_r], self.true_out[r][:c_r])) and int(views[r][2][:c_r].abs().sum()) == 0
+            t = torch.tensor([1.0 if ok else 0.0], device=self.d_lag.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            ok = bool(t.item() == 1.0)
+        return ok
+
+    def kernel_medians(self, steps):
+        """per-kernel HIP-event durations of `steps` CONSECUTIVE steps (no host sync between them): medians"""
+        torch = self.torch
+        self.plan.set_profiling(steps)
+        for _ in range(steps):
+            self.step()
+        torch.cuda.synchronize()
+        rows = [self.plan.last_timings_ms(b) for b in range(steps)]
+        self.plan.set_profiling(0)
+        return ({k: statistics.median(r[k] for r in rows) for k in FAMILIES},
+                {k: [min(r[k] for r in rows), max(r[k] for r in rows)] for k in FAMILIES})
+
+    def close(self):
+        self.plan.close()
+        del self.d_src, self.d_smp
+
+
+def traffic_from_profiles(n, split, group, dom):
+    """HBM bytes per launch of the dominant kernel from the committed PMC run (tools/traffic.sh: separate --pmc
+    passes, FETCH_SIZE / WRITE_SIZE corrected as MI355X_MICROARCH.md prescribes) -- NOT measured in this run;
+    only returned when that run was this workload (sample_len, split, group)."""
+    for name in ("r2_traffic.json", "r1_traffic.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(path):
+            continue
+        tj = json.load(open(path))
+        c = tj.get("config", {})
+        if c.get("sample_len") == n and c.get("split") == split and c.get("group") == group:
+            for kname, kv in tj["kernels"].items():
+                if kname.startswith("k_" + dom):
+                    return kv["hbm_bytes_per_launch"], "profiles/%s (PMC run of %s, commit %s)" % (name, tj.get("date", "?"), tj.get("commit", "?"))
+    return None, None
+
+
+def run_rank(args):
     import torch
     import torch.distributed as dist
     import __graft_entry__ as graft
@@ -163,121 +378,122 @@ def main():
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
+    stream = torch.cuda.Stream(dev)          # explicit: the library and the collective share THIS stream
+    line = None
+    with torch.cuda.stream(stream):
+        n = args.sample_len
+        batch = args.batch or max(8, min(4096, (2 << 30) // (12 * n)))   # ~2 GiB of inputs per GPU
+        w = Workload(asx, sharding, torch, dist, dev, stream, n, batch * world, world, rank, multi, args.noise_shift, args.split)
+        dt = w.timed(args.steps, args.warmup)
+        ok = w.verify()
+        med, spread = w.kernel_medians(max(20, args.steps))
+        plan_group, plan_split, plan_threads = w.plan.group, w.plan.split, w.plan.threads
+        overflows = w.plan.peak_overflows()
+        w.close()
+        torch.cuda.empty_cache()
 
-    n = args.sample_len
-    batch = args.batch or max(8, min(4096, (2 << 30) // (12 * n)))   # ~2 GiB of inputs per GPU
-    d_src = torch.empty(batch * 2 * n, dtype=torch.float32, device=dev)
-    d_smp = torch.empty(batch * n, dtype=torch.float32, device=dev)
-    d_true = torch.empty(batch, dtype=torch.int64, device=dev)
-    # a shard's results live back to back in one byte buffer so that the gather is ONE collective with
-    # no packing kernels (sharding.result_buffer)
-    res_buf, (d_lag, d_coef, d_ret) = sharding.result_buffer(batch, dev)
-    gather_out = torch.empty((world, sharding.result_bytes(batch)), dtype=torch.uint8, device=dev) if multi else None
-    gathered = [None]
-    stream = torch.cuda.current_stream().cuda_stream
-    # distinct pairs on every rank: pair ids [rank*batch, (rank+1)*batch)
-    asx.synth_pairs_dev(20260101, rank * batch, batch, n, args.noise_shift, d_src.data_ptr(),
-                        d_smp.data_ptr(), d_true.data_ptr(), stream)
-    plan = asx.Plan(n, batch, torch.cuda.current_device(), split=args.split)
+        cfg4 = None
+        if not args.no_config4:
+            w4 = Workload(asx, sharding, torch, dist, dev, stream, CONFIG4_N, CONFIG4_BATCH, world, rank, multi, 0, None)
+            dt4 = w4.timed(args.steps4, 1)
+            ok4 = w4.verify()
+            cfg4 = {"metric": "cross-correlations/sec (fixed batch %d x N=%d, strong scaling)" % (CONFIG4_BATCH, CONFIG4_N),
+                    "value": CONFIG4_BATCH * args.steps4 / dt4, "unit": "cross-correlations/s", "scaling": "strong",
+                    "n_gpus": world, "steps": args.steps4, "ms_per_step": dt4 / args.steps4 * 1e3,
+                    "pairs_per_gpu": w4.count, "results_ok": ok4,
+                    "path_frac_of_hbm_roofline": BYTES_PER_FRAME * CONFIG4_N * CONFIG4_BATCH * args.steps4 / dt4 / world / 1e9 / HBM_PEAK_GBS,
+                    "workload": "BASELINE configs[3]: %d pairs, N=%d, SNR -6 dB, block-partitioned over %d rank(s), inputs "
+                                "generated on the device per shard (%.1f GB per rank), result all-gather timed" %
+                                (CONFIG4_BATCH, CONFIG4_N, world, 12.0 * CONFIG4_N * w4.count / 1e9)}
+            w4.close()
+            torch.cuda.empty_cache()
 
-    def step():
-        plan.xcorr_batch_dev(d_src.data_ptr(), d_smp.data_ptr(), batch, d_lag.data_ptr(),
-                             d_coef.data_ptr(), d_ret.data_ptr(), stream)
-        if multi:
-            # the only exchange on this path: RCCL all-gather of the 20 result bytes per pair of every
-            # shard, in stream order behind the kernels that produce them
-            gathered[0] = sharding.gather_result_buffers(res_buf, batch, out=gather_out)
+        single = None
+        if world == 1 and not args.no_single:
+            import numpy as np
+            s32 = torch.empty(2 * n, dtype=torch.float32, device=dev); t32 = torch.empty(n, dtype=torch.float32, device=dev)
+            asx.synth_pairs_dev(SEED, 0, 1, n, 1, s32.data_ptr(), t32.data_ptr(), 0, stream.cuda_stream)
+            torch.cuda.synchronize()
+            single = single_pair_latency(asx, torch, s32.cpu().numpy(), t32.cpu().numpy(), n, 10)
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if multi:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if multi:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if multi:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-
-    # correctness of what was timed: the planted delays
-    ok = bool(torch.equal(d_lag, d_true)) and int(d_ret.abs().sum()) == 0
-    if multi and gathered[0] is not None:   # ... and this rank's slice of what the gather delivered
-        views = gathered[0][1]
-        ok = ok and len(views) == world and bool(torch.equal(views[rank][0], d_true))
-
-    # per-kernel durations, HIP events on the stream the kernels ran on (one extra profiled step)
-    plan.set_profiling(True)
-    step()
-    torch.cuda.synchronize()
-    timings = plan.last_timings_ms()
-    plan.set_profiling(False)
-
+        if rank == 0:
+            value = batch * world * args.steps / dt
+            groups = (batch + plan_group - 1) // plan_group
+            per_launch_pairs = min(batch, plan_group)
+            dom = max(("fwd_cols", "rows", "inv_cols", "pearson"), key=lambda k: med[k])
+            dom_launch_ms = med[dom] / groups
+            dom_bytes = ALGO_SHARE[dom] * n * per_launch_pairs
+            achieved = dom_bytes / (dom_launch_ms * 1e-3) / 1e9
+            path_gbs = BYTES_PER_FRAME * n * value / world / 1e9   # per GPU, from the timed steps
+            split = "%dx%dx%d" % plan_split
+            traffic, traffic_src = traffic_from_profiles(n, split, plan_group, dom)
+            ksum = sum(med[k] for k in ("fwd_cols", "rows", "inv_cols", "finalize", "pearson"))
+            roofline = {
+                "bound": "hbm", "kernel": "k_" + dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": dom_launch_ms,
+                "launches_per_step": groups, "pairs_per_launch": per_launch_pairs,
+                "path": {"algorithmic_bytes_per_pair": BYTES_PER_FRAME * n, "achieved": path_gbs,
+                         "frac": path_gbs / HBM_PEAK_GBS,
+                         "basis": "52*N bytes per pair x pairs/s per GPU over the timed steps"},
+                "kernel_ms_per_step": med, "kernel_ms_min_max": spread, "kernel_ms_sum": ksum,
+                "kernel_ms_basis": "HIP events on the launch stream, median over %d consecutive steps after the timed "
+                                   "region (no host sync between them)" % max(20, args.steps),
+            }
+            line = {
+                "metric": "cross-correlations/sec (N=%d float32 pairs)" % n,
+                "value": value, "unit": "cross-correlations/s", "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+                "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": "batched xcorr, N=%d frames/sample (source 2N), %d pairs per GPU per step, "
+                                       "48 kHz mono float32, planted delays, SNR 0 dB" % (n, batch),
+                           "sample_len": n, "pairs_per_gpu": batch, "group": plan_group,
+                           "split": split, "threads_cols_rows": list(plan_threads),
+                           "parallelism": "pairs sharded over %d GPU(s), one process per GPU, RCCL all_gather of results" % world},
+                "world_size_seen": dist.get_world_size() if multi else 1,
+                "results_ok": ok, "peak_overflows": overflows,
+                "roofline": roofline,
+            }
+            if cfg4 is not None:
+                line["config4"] = cfg4
+            if single is not None:
+                line["single_pair"] = single
     if rank == 0:
-        pairs_total = batch * world * args.steps
-        value = pairs_total / dt
-        groups = (batch + plan.group - 1) // plan.group
-        per_launch_pairs = min(batch, plan.group)
-        fam = ("fwd_cols", "rows", "inv_cols", "pearson")
-        dom = max(fam, key=lambda k: timings[k])
-        # DESIGN.md "Algorithmic bytes": A(N) = 52*N per cross-correlation, attributed
-        # to the kernel that moves them: fwd_cols 28N (inputs in, both spectra out), rows 16N (both
-        # spectra in), inv_cols 0 (its 8N read is an intermediate, not algorithmic), pearson 8N.
-        algo_share = {"fwd_cols": 28, "rows": 16, "inv_cols": 0, "pearson": 8}
-        dom_launch_ms = timings[dom] / groups
-        dom_bytes = algo_share[dom] * n * per_launch_pairs
-        achieved = dom_bytes / (dom_launch_ms * 1e-3) / 1e9
-        path_gbs = BYTES_PER_FRAME * n * value / world / 1e9   # per GPU, from the timed steps
-        m1, m2, tcols = plan.split
-        split = "%dx%dx%d" % (m1, m2, tcols)
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r1_traffic.json")
-        if os.path.exists(tpath):
-            # HBM bytes per launch from the PMC counters (tools/traffic.sh: separate --pmc passes,
-            # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes); only if it is this workload
-            tj = json.load(open(tpath))
-            c = tj.get("config", {})
-            if c.get("sample_len") == n and c.get("split") == split and c.get("group") == plan.group:
-                for kname, kv in tj["kernels"].items():
-                    if kname.startswith("k_" + dom):
-                        traffic = kv["hbm_bytes_per_launch"]
-        roofline = {
-            "bound": "hbm", "kernel": "k_" + dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-            "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": dom_launch_ms,
-            "launches_per_step": groups, "pairs_per_launch": per_launch_pairs,
-            "path": {"algorithmic_bytes_per_pair": BYTES_PER_FRAME * n, "achieved": path_gbs,
-                     "frac": path_gbs / HBM_PEAK_GBS,
-                     "basis": "52*N bytes per pair x pairs/s per GPU over the timed steps; kernel_ms_per_step is one extra event-timed step"},
-            "kernel_ms_per_step": {k: timings[k] for k in ("fwd_cols", "rows", "inv_cols", "finalize", "pearson", "total")},
-        }
-        line = {
-            "metric": "cross-correlations/sec (N=%d float32 pairs)" % n,
-            "value": value, "unit": "cross-correlations/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "batched xcorr, N=%d frames/sample (source 2N), %d pairs per GPU per step, "
-                                   "48 kHz mono float32, planted delays, SNR 0 dB" % (n, batch),
-                       "sample_len": n, "pairs_per_gpu": batch, "group": plan.group,
-                       "split": split, "threads_cols_rows": list(plan.threads),
-                       "parallelism": "pairs sharded over %d GPU(s), RCCL all_gather of results" % world},
-            "results_ok": ok,
-            "roofline": roofline,
-        }
         if world == 1 and not args.no_cpu:
-            line["cpu_baseline"] = cpu_baseline(n)
+            line["cpu_baseline"] = cpu_baseline(args.sample_len)
         print(json.dumps(line), flush=True)
-    plan.close()
     if multi:
+        dist.barrier()
         dist.destroy_process_group()
+    return 0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--sample-len", type=int, default=1440000)
+    ap.add_argument("--batch", type=int, default=0, help="pairs per GPU per step (0 = auto)")
+    ap.add_argument("--noise-shift", type=int, default=1)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-config4", action="store_true", help="skip the fixed-batch 8192 x 480000 leg")
+    ap.add_argument("--no-single", action="store_true", help="skip the single-pair latency leg")
+    ap.add_argument("--steps4", type=int, default=3, help="timed steps of the config4 leg")
+    ap.add_argument("--split", default=None)
+    ap.add_argument("--dry-run", action="store_true", help="rank/shard/gather path on CPU with gloo, no GPU")
+    ap.add_argument("--mode", default="batched", choices=["batched", "streaming", "single"],
+                    help="batched = the headline workload (default); streaming = BASELINE config 5 "
+                         "(growing window 3..30 s, plan reuse); single = config 2 (one pair, latency)")
+    args = ap.parse_args()
+    if args.mode != "batched":
+        return side_mode(args)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return spawn_ranks(args, sys.argv[1:])
+    if args.dry_run:
+        return dry_run(args)
+    return run_rank(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

@@ -173,11 +173,14 @@ int asx_synth_pairs_dev(uint64_t seed, uint64_t first_pair, size_t count, size_t
                         int noise_shift, float *d_source, float *d_sample, int64_t *d_true_lag,
                         void *stream);
 
-/* Milliseconds spent by the most recent asx_xcorr_batch_f32_dev call on
- * `plan`, per kernel family, measured with HIP events on the stream the
- * kernels ran on.  Only filled when profiling was enabled before the call.
- * out[0..5] = fwd_cols, rows, inv_cols, finalize, pearson, total. */
-int asx_plan_set_profiling(asx_plan *plan, int enabled);
+/* Milliseconds spent by recent asx_xcorr_batch_f32_dev calls on `plan`, per kernel family, measured
+ * with HIP events on the stream the kernels ran on.  asx_plan_set_profiling(plan, depth): depth > 0
+ * keeps the events of the last `depth` calls (so that consecutive steps can be timed with no host
+ * synchronisation between them), 0 switches profiling off.  asx_plan_timings_ms(plan, calls_back, out):
+ * the call `calls_back` calls ago (0 = the latest); asx_plan_last_timings_ms = calls_back 0.
+ * out[0..5] = fwd_cols, rows, inv_cols, finalize (+ exact re-evaluation), pearson, total. */
+int asx_plan_set_profiling(asx_plan *plan, int depth);
+int asx_plan_timings_ms(asx_plan *plan, int calls_back, float out[6]);
 int asx_plan_last_timings_ms(asx_plan *plan, float out[6]);
 
 /* Raw device memory helpers so a C host (no torch) can stage buffers. */

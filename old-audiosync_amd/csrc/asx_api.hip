@@ -112,9 +112,14 @@ struct asx_plan {
     int32_t *st_ret = nullptr;
     double *st_src64 = nullptr, *st_smp64 = nullptr;
 
+    // Profiling: HIP events around every kernel family, on the stream the kernels run on.  A ring of
+    // the last `prof_depth` batch calls is kept so that consecutive steps can be timed without a
+    // host synchronisation between them (6 events per group, the first ASX_PROF_GROUPS groups of a call).
     bool profiling = false;
-    std::vector<hipEvent_t> ev;      // 6 per group of the last call
-    size_t ev_groups = 0;
+    size_t prof_depth = 1, prof_calls = 0, prof_base = 0;
+    std::vector<hipEvent_t> ev;
+    std::vector<size_t> prof_groups; // groups recorded by the call in ring slot i
+    size_t ev_groups = 0;            // groups recorded by the call in progress / the latest call
 };
 
 template <typename T> static int dev_alloc(asx_plan *p, T **out, size_t count)
@@ -408,9 +413,28 @@ extern "C" int asx_plan_split(const asx_plan *p, int *m1, int *m2, int *tile_col
 // ---------------------------------------------------------------------------
 // running groups
 // ---------------------------------------------------------------------------
+#define ASX_PROF_GROUPS 16
+static void prof_begin_call(asx_plan *p)
+{
+    p->ev_groups = 0;
+    if (!p->profiling) return;
+    const size_t ring = p->prof_calls % p->prof_depth;
+    p->prof_base = ring * ASX_PROF_GROUPS * 6;
+    if (p->prof_groups.size() < p->prof_depth) p->prof_groups.resize(p->prof_depth, 0);
+    p->prof_groups[ring] = 0;
+}
+static void prof_end_call(asx_plan *p, size_t groups)
+{
+    if (!p->profiling) return;
+    p->ev_groups = std::min<size_t>(groups, ASX_PROF_GROUPS);
+    p->prof_groups[p->prof_calls % p->prof_depth] = p->ev_groups;
+    p->prof_calls++;
+}
+
 static int prof_mark(asx_plan *p, hipStream_t s, size_t slot)
 {
-    if (!p->profiling) return 0;
+    if (!p->profiling || slot >= ASX_PROF_GROUPS * 6) return 0;
+    slot += p->prof_base;
     while (p->ev.size() <= slot) {
         hipEvent_t ev;
         HIP_TRY(hipEventCreate(&ev));
@@ -463,7 +487,7 @@ extern "C" int asx_xcorr_batch_f32_dev(asx_plan *p, const float *d_source, const
     if (!dg.ok) return fail("cannot select device %d", p->device);
     hipStream_t s = stream ? (hipStream_t)stream : p->stream;
     const size_t N = p->host.N;
-    p->ev_groups = 0;
+    prof_begin_call(p);
     // chunking: groups of at most `group` pairs; with two lanes a batch is cut into at least two
     // chunks (when it is big enough to fill the chip twice) that alternate between the lanes
     const bool overlap = (p->nlanes == 2) && !p->profiling && batch >= 8;
@@ -489,7 +513,7 @@ extern "C" int asx_xcorr_batch_f32_dev(asx_plan *p, const float *d_source, const
             HIP_TRY(hipStreamWaitEvent(s, p->lanes[l].done, 0));
         }
     }
-    p->ev_groups = p->profiling ? gi : 0;
+    prof_end_call(p, gi);
     return 0;
 }
 
@@ -502,8 +526,10 @@ extern "C" int asx_xcorr_debug_r_dev(asx_plan *p, const float *d_source, const f
     DevGuard dg(p->device);
     if (!dg.ok) return fail("cannot select device %d", p->device);
     hipStream_t s = stream ? (hipStream_t)stream : p->stream;
-    p->ev_groups = 0;
-    return run_group<float>(p, d_source, d_sample, d_source, d_sample, 1, d_lag, d_coef, d_ret, d_r, s, 0);
+    prof_begin_call(p);
+    const int rc = run_group<float>(p, d_source, d_sample, d_source, d_sample, 1, d_lag, d_coef, d_ret, d_r, s, 0);
+    prof_end_call(p, 1);
+    return rc;
 }
 
 static int ensure_staging(asx_plan *p)
@@ -526,7 +552,7 @@ extern "C" int asx_xcorr_batch_f32(asx_plan *p, const float *source, const float
     if (ensure_staging(p)) return -1;
     const size_t N = p->host.N;
     hipStream_t s = p->stream;
-    p->ev_groups = 0;
+    prof_begin_call(p);
     for (size_t done = 0; done < batch; done += p->group) {
         const size_t g = std::min(p->group, batch - done);
         HIP_TRY(hipMemcpyAsync(p->st_src, source + done * 2 * N, g * 2 * N * sizeof(float), hipMemcpyHostToDevice, s));
@@ -555,7 +581,7 @@ extern "C" int asx_xcorr_f64(asx_plan *p, const double *source, const double *sa
         if (dev_alloc(p, &p->st_src64, 2 * N) || dev_alloc(p, &p->st_smp64, N)) return -1;
     }
     hipStream_t s = p->stream;
-    p->ev_groups = 0;
+    prof_begin_call(p);
     HIP_TRY(hipMemcpyAsync(p->st_src64, source, 2 * N * sizeof(double), hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(p->st_smp64, sample, N * sizeof(double), hipMemcpyHostToDevice, s));
     asx_launch_cvt_f64_f32(p->st_src64, p->st_src, 2 * N, s);
@@ -753,7 +779,7 @@ extern "C" int asx_stream_xcorr(asx_stream *st, size_t sample_len, long *lag, do
     DevGuard dg(st->device);
     if (!dg.ok) return fail("cannot select device %d", st->device);
     hipStream_t s = p->stream;
-    p->ev_groups = 0;
+    prof_begin_call(p);
     if (run_group<double>(p, st->src32, st->smp32, st->src64, st->smp64, 1, st->d_lag, st->d_coef, st->d_ret,
                           nullptr, s, 0))
         return -1;
@@ -788,35 +814,46 @@ extern "C" int asx_synth_pairs_dev(uint64_t seed, uint64_t first_pair, size_t co
     return 0;
 }
 
-extern "C" int asx_plan_set_profiling(asx_plan *p, int enabled)
+extern "C" int asx_plan_set_profiling(asx_plan *p, int depth)
 {
     if (!p) return -1;
     std::lock_guard<std::mutex> guard(p->lock);
-    p->profiling = enabled != 0;
+    p->profiling = depth > 0;
+    p->prof_depth = depth > 0 ? (size_t)depth : 1;
+    p->prof_calls = 0;
+    p->prof_groups.assign(p->prof_depth, 0);
     p->ev_groups = 0;
     return 0;
 }
 
-extern "C" int asx_plan_last_timings_ms(asx_plan *p, float out[6])
+// timings of the batch call `calls_back` calls ago (0 = the latest) of the profiling ring
+extern "C" int asx_plan_timings_ms(asx_plan *p, int calls_back, float out[6])
 {
     if (!p || !out) return -1;
     std::lock_guard<std::mutex> guard(p->lock);
     for (int i = 0; i < 6; i++) out[i] = 0.f;
-    if (p->ev_groups == 0) return fail("no profiled call recorded");
+    if (!p->profiling || calls_back < 0 || (size_t)calls_back >= p->prof_depth || (size_t)calls_back >= p->prof_calls)
+        return fail("no profiled call recorded %d calls back", calls_back);
+    const size_t ring = (p->prof_calls - 1 - (size_t)calls_back) % p->prof_depth;
+    const size_t groups = p->prof_groups[ring];
+    if (groups == 0) return fail("no profiled call recorded");
+    const hipEvent_t *ev = p->ev.data() + ring * ASX_PROF_GROUPS * 6;
     DevGuard dg(p->device);
-    for (size_t g = 0; g < p->ev_groups; g++) {
-        HIP_TRY(hipEventSynchronize(p->ev[g * 6 + 5]));
+    for (size_t g = 0; g < groups; g++) {
+        HIP_TRY(hipEventSynchronize(ev[g * 6 + 5]));
         for (int k = 0; k < 5; k++) {
             float ms = 0.f;
-            HIP_TRY(hipEventElapsedTime(&ms, p->ev[g * 6 + k], p->ev[g * 6 + k + 1]));
+            HIP_TRY(hipEventElapsedTime(&ms, ev[g * 6 + k], ev[g * 6 + k + 1]));
             out[k] += ms;
         }
     }
     float total = 0.f;
-    HIP_TRY(hipEventElapsedTime(&total, p->ev[0], p->ev[(p->ev_groups - 1) * 6 + 5]));
+    HIP_TRY(hipEventElapsedTime(&total, ev[0], ev[(groups - 1) * 6 + 5]));
     out[5] = total;
     return 0;
 }
+
+extern "C" int asx_plan_last_timings_ms(asx_plan *p, float out[6]) { return asx_plan_timings_ms(p, 0, out); }
 
 extern "C" void *asx_device_malloc(size_t bytes, int device)
 {

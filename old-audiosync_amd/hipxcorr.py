@@ -24,7 +24,7 @@ ABI_SYMBOLS = [
     "asx_stream_append_f64", "asx_stream_lengths", "asx_stream_reset", "asx_stream_xcorr", "asx_synth_pairs_dev", "asx_plan_set_profiling",
     "asx_plan_last_timings_ms", "asx_device_malloc", "asx_device_free", "asx_memcpy_h2d",
     "asx_memcpy_d2h", "asx_stream_sync", "asx_plan_peak_overflows", "asx_plan_peak_capacity",
-    "asx_current_device",
+    "asx_current_device", "asx_plan_timings_ms",
 ]
 
 
@@ -107,6 +107,8 @@ def lib():
     L.asx_plan_set_profiling.argtypes = [vp, ctypes.c_int]
     L.asx_plan_last_timings_ms.restype = ctypes.c_int
     L.asx_plan_last_timings_ms.argtypes = [vp, c_f32p]
+    L.asx_plan_timings_ms.restype = ctypes.c_int
+    L.asx_plan_timings_ms.argtypes = [vp, ctypes.c_int, c_f32p]
     L.asx_device_malloc.restype = vp
     L.asx_device_malloc.argtypes = [ctypes.c_size_t, ctypes.c_int]
     L.asx_device_free.restype = ctypes.c_int
@@ -355,12 +357,13 @@ class Plan:
         if rc != 0:
             raise AsxError(_err())
 
-    def set_profiling(self, on):
-        lib().asx_plan_set_profiling(self._h, 1 if on else 0)
+    def set_profiling(self, depth):
+        """depth > 0: keep the kernel events of the last `depth` batch calls; 0 / False: off"""
+        lib().asx_plan_set_profiling(self._h, int(depth))
 
-    def last_timings_ms(self):
+    def last_timings_ms(self, calls_back=0):
         out = (ctypes.c_float * 6)()
-        rc = lib().asx_plan_last_timings_ms(self._h, out)
+        rc = lib().asx_plan_timings_ms(self._h, int(calls_back), out)
         if rc != 0:
             raise AsxError(_err())
         return dict(zip(("fwd_cols", "rows", "inv_cols", "finalize", "pearson", "total"), list(out)))

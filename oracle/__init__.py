@@ -17,7 +17,7 @@ _lib = None
 
 def build(force=False):
     """compile liboracle.so with the committed Makefile (gcc only)."""
-    srcs = [os.path.join(_HERE, f) for f in ("fft64.c", "xcorr_oracle.c", "fft64.h", "xcorr_oracle.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("fft64.c", "xcorr_oracle.c", "cpu_baseline.c", "fft64.h", "xcorr_oracle.h")]
     stale = (not os.path.exists(_LIB_PATH)) or any(
         os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs)
     if force or stale:
@@ -48,6 +48,10 @@ def lib():
         L.oracle_synth_pair.restype = None
         L.oracle_synth_pair.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_size_t,
                                         ctypes.c_int, fp, fp, ctypes.POINTER(ctypes.c_int64)]
+        L.oracle_cross_correlation_faithful.restype = ctypes.c_int
+        L.oracle_cross_correlation_faithful.argtypes = [dp, dp, ctypes.c_size_t,
+                                                        ctypes.POINTER(ctypes.c_long), dp]
+        L.oracle_baseline_backend.restype = ctypes.c_char_p
         L.offt_rfft.restype = ctypes.c_int
         L.offt_rfft.argtypes = [ctypes.c_size_t, dp, ctypes.c_void_p]
         L.offt_irfft.restype = ctypes.c_int
@@ -96,6 +100,22 @@ def cross_correlation(source, sample, want_results=False):
     ret = lib().oracle_cross_correlation_ex(_d(s), _d(t), n, ctypes.byref(lag), ctypes.byref(coef),
                                             _d(r), ctypes.byref(margin))
     return ret, lag.value, coef.value, r, margin.value
+
+
+def baseline_backend():
+    """"fftw3" when libfftw3.so.3 could be dlopen()ed on this node, else "port" (oracle/fft64.c)"""
+    return lib().oracle_baseline_backend().decode()
+
+
+def cross_correlation_faithful(source, sample):
+    """one call with the reference's cost model (two threads, plan per call, allocations per call)"""
+    s = np.ascontiguousarray(source, dtype=np.float64)
+    t = np.ascontiguousarray(sample, dtype=np.float64)
+    assert s.size == 2 * t.size
+    lag = ctypes.c_long(0)
+    coef = ctypes.c_double(0.0)
+    ret = lib().oracle_cross_correlation_faithful(_d(s), _d(t), t.size, ctypes.byref(lag), ctypes.byref(coef))
+    return ret, lag.value, coef.value
 
 
 def synth_pair(seed, pair, n, noise_shift=1):

@@ -44,6 +44,14 @@ int oracle_cross_correlation_ex(const double *source, const double *sample, size
 int oracle_cross_correlation_f32(const float *source, const float *sample, size_t sample_len,
                                  long *lag, double *coefficient);
 
+/* bench.py's cpu_baseline leg (cpu_baseline.c): one call with the reference's own cost model -- four
+ * allocations, two threads that each plan + execute a forward transform, plan + execute the inverse,
+ * everything released again (src/cross_correlation.c:26-46,159-239,300-304).  The transform backend is
+ * real FFTW3 when libfftw3.so.3 can be dlopen()ed on the node, else this directory's own DFT. */
+int oracle_cross_correlation_faithful(const double *source, const double *sample, size_t sample_len,
+                                      long *lag, double *coefficient);
+const char *oracle_baseline_backend(void); /* "fftw3" or "port" */
+
 /* Deterministic synthetic pair generator, integer-exact so the
  * HIP generator (csrc/synth.hip) reproduces it bit for bit:
  *   u(i)      = 24-bit uniform in [-1,1) from splitmix64(key_sig + i),  i in [0,3N)

@@ -1,0 +1,42 @@
+"""bench.py's N>1 launcher on CPU: `--gpus 2` must start two ranks (one process each) that form a
+process group, shard both workloads and gather every shard's results -- here with gloo and fabricated
+results (`--dry-run`), the same code path the GPU run takes with RCCL."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(*argv, env_extra=None):
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(argv), cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=600)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    return p, (json.loads(lines[-1]) if lines else None)
+
+
+def test_gpus_2_launches_two_ranks():
+    p, line = run_bench("--gpus", "2", "--dry-run")
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert line is not None, p.stdout[-2000:] + p.stderr[-2000:]
+    assert line["dry_run"] is True and line["n_gpus"] == 2 and line["world_size_seen"] == 2
+    assert line["results_ok"] is True
+    assert line["shards_rank0"]["config4"] == {"total": 8192, "shard": [0, 4096]}
+
+
+def test_gpus_3_uneven_shards():
+    p, line = run_bench("--gpus", "3", "--dry-run")
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert line["n_gpus"] == 3 and line["results_ok"] is True
+    assert line["shards_rank0"]["config4"] == {"total": 8192, "shard": [0, 2731]}
+
+
+def test_a_failing_rank_fails_the_launcher():
+    # a rank that cannot form the group (bad backend request) must surface as a non-zero exit code
+    p, line = run_bench("--gpus", "2", "--dry-run", env_extra={"ASX_BENCH_DRYRUN_FAIL": "1"})
+    assert p.returncode != 0
