@@ -116,6 +116,14 @@ int asx_xcorr_batch_f32_dev(asx_plan *plan, const float *d_source, const float *
                             size_t batch, int64_t *d_lag, double *d_coef, int32_t *d_ret,
                             void *stream);
 
+/* The batched variant over several GPUs of one node from ONE process (BASELINE.json north_star; no
+ * reference equivalent): plans[i] was created on device i (any devices; all the same sample_len); the
+ * batch is block-partitioned over the plans, each block runs concurrently on its device, results come
+ * back in pair order.  Pairs are independent: nothing is exchanged between devices.  (bench.py uses
+ * one process per GPU and RCCL for the result gather instead; this is the entry point for C hosts.) */
+int asx_xcorr_batch_multi(asx_plan *const *plans, int nplans, const float *source, const float *sample,
+                          size_t batch, int64_t *lag, double *coef, int32_t *ret);
+
 /* Debug/parity aid: run ONE device-resident pair and also return the raw
  * correlation r[0..2N) (device pointer, 2N floats; scaled by F/(2N) relative
  * to the reference when the length had to be embedded). */

@@ -13,6 +13,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 // ---------------------------------------------------------------------------
@@ -565,6 +566,39 @@ extern "C" int asx_xcorr_batch_f32(asx_plan *p, const float *source, const float
         HIP_TRY(hipMemcpyAsync(ret + done, p->st_ret, g * sizeof(int32_t), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
     }
+    return 0;
+}
+
+// Several plans (normally one per GPU of the node) in ONE process: the batch is block-partitioned over
+// them (the first batch % nplans plans get one pair more), every block runs on its plan's device from
+// its own host thread, and the results land in the caller's arrays in pair order -- the "gather" of a
+// single process is the D2H copy.  No data-path exchange between devices.
+extern "C" int asx_xcorr_batch_multi(asx_plan *const *plans, int nplans, const float *source, const float *sample,
+                                     size_t batch, int64_t *lag, double *coef, int32_t *ret)
+{
+    if (!plans || nplans < 1 || !source || !sample || !lag || !coef || !ret) return fail("asx_xcorr_batch_multi: bad argument");
+    const size_t N = plans[0] ? plans[0]->host.N : 0;
+    for (int i = 0; i < nplans; i++)
+        if (!plans[i] || plans[i]->host.N != N) return fail("asx_xcorr_batch_multi: plans must share one sample_len");
+    std::vector<int> rc((size_t)nplans, 0);
+    std::vector<std::string> err((size_t)nplans);
+    std::vector<std::thread> workers;
+    const size_t base = batch / (size_t)nplans, extra = batch % (size_t)nplans;
+    size_t start = 0;
+    for (int i = 0; i < nplans; i++) {
+        const size_t count = base + ((size_t)i < extra ? 1 : 0);
+        if (count) {
+            workers.emplace_back([=, &rc, &err]() {
+                rc[(size_t)i] = asx_xcorr_batch_f32(plans[i], source + start * 2 * N, sample + start * N, count,
+                                                    lag + start, coef + start, ret + start);
+                if (rc[(size_t)i] != 0) err[(size_t)i] = asx_last_error(); // the worker thread's message
+            });
+        }
+        start += count;
+    }
+    for (std::thread &t : workers) t.join();
+    for (int i = 0; i < nplans; i++)
+        if (rc[(size_t)i] != 0) return fail("asx_xcorr_batch_multi: plan %d: %s", i, err[(size_t)i].c_str());
     return 0;
 }
 

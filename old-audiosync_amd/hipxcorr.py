@@ -24,7 +24,7 @@ ABI_SYMBOLS = [
     "asx_stream_append_f64", "asx_stream_lengths", "asx_stream_reset", "asx_stream_xcorr", "asx_synth_pairs_dev", "asx_plan_set_profiling",
     "asx_plan_last_timings_ms", "asx_device_malloc", "asx_device_free", "asx_memcpy_h2d",
     "asx_memcpy_d2h", "asx_stream_sync", "asx_plan_peak_overflows", "asx_plan_peak_capacity",
-    "asx_current_device", "asx_plan_timings_ms",
+    "asx_current_device", "asx_plan_timings_ms", "asx_xcorr_batch_multi",
 ]
 
 
@@ -80,6 +80,8 @@ def lib():
     L.asx_xcorr_f64.argtypes = [vp, c_f64p, c_f64p, ctypes.POINTER(ctypes.c_long), c_f64p]
     L.asx_xcorr_batch_f32.restype = ctypes.c_int
     L.asx_xcorr_batch_f32.argtypes = [vp, c_f32p, c_f32p, ctypes.c_size_t, c_i64p, c_f64p, c_i32p]
+    L.asx_xcorr_batch_multi.restype = ctypes.c_int
+    L.asx_xcorr_batch_multi.argtypes = [ctypes.POINTER(vp), ctypes.c_int, c_f32p, c_f32p, ctypes.c_size_t, c_i64p, c_f64p, c_i32p]
     L.asx_xcorr_batch_f32_dev.restype = ctypes.c_int
     L.asx_xcorr_batch_f32_dev.argtypes = [vp, vp, vp, ctypes.c_size_t, vp, vp, vp, vp]
     L.asx_xcorr_debug_r_dev.restype = ctypes.c_int
@@ -218,6 +220,24 @@ def synth_pairs_dev(seed, first_pair, count, sample_len, noise_shift, d_src, d_s
                                    d_lag or None, stream or None)
     if rc != 0:
         raise AsxError(_err())
+
+
+def xcorr_batch_multi(plans, source, sample):
+    """host float32 arrays [B,2N], [B,N] block-partitioned over `plans` (one per device) -> (lag, coef, ret)"""
+    s = np.ascontiguousarray(source, dtype=np.float32)
+    t = np.ascontiguousarray(sample, dtype=np.float32)
+    n = plans[0].sample_len
+    batch = t.size // n
+    assert t.size == batch * n and s.size == 2 * n * batch
+    lag = np.zeros(batch, dtype=np.int64)
+    coef = np.zeros(batch, dtype=np.float64)
+    ret = np.zeros(batch, dtype=np.int32)
+    handles = (ctypes.c_void_p * len(plans))(*[p._h for p in plans])
+    rc = lib().asx_xcorr_batch_multi(handles, len(plans), s.ctypes.data_as(c_f32p), t.ctypes.data_as(c_f32p), batch,
+                                     lag.ctypes.data_as(c_i64p), coef.ctypes.data_as(c_f64p), ret.ctypes.data_as(c_i32p))
+    if rc != 0:
+        raise AsxError(_err())
+    return lag, coef, ret
 
 
 class Stream:

@@ -5,17 +5,27 @@
  * returns (lag:int, success:bool) like the "lO" of src/bind.c:107), every C call made with the
  * GIL released like src/bind.c:102-104.  Two additions, because the reference never exposed
  * the hot path to Python:
- *   cross_correlation(source, sample) -> (ret, lag, coefficient)   float64 buffers, len(source) == 2*len(sample)
+ *   cross_correlation(source, sample) -> (ret, lag, coefficient)   float64 or float32 buffers,
+ *                                                                   len(source) == 2*len(sample)
+ *   cross_correlation_batch(sources, samples) -> (rets, lags, coefficients)
+ *                                                                   B pairs: sources [B][2N], samples [B][N]
+ *                                                                   (any C-contiguous buffers of that many
+ *                                                                   float32 or float64 values; 1-D or 2-D)
  *   set_feed(source, sample, frames_per_ms=0)                      tracks that run() will consume
+ * float64 goes through cross_correlation(double*) (transforms in float32, Pearson on the doubles);
+ * float32 goes through asx_xcorr_batch_f32 (one launch group per call, the batched path of the benchmark).
  */
 #define PY_SSIZE_T_CLEAN
 #include <Python.h>
 
+#include <pthread.h>
+#include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
 
 #include <audiosync/audiosync.h>
 #include <audiosync/cross_correlation.h>
+#include <audiosync/xcorr_hip.h>
 
 /* copies of the fed tracks: run() may outlive the Python objects that were passed in */
 static double *feed_source_copy, *feed_sample_copy;
@@ -108,15 +118,56 @@ static int as_doubles(PyObject *obj, Py_buffer *view, const char *what)
     return 0;
 }
 
+/* float64 ("d") or float32 ("f") C-contiguous buffer; returns the item size (8 / 4) or -1 */
+static int as_reals(PyObject *obj, Py_buffer *view, const char *what)
+{
+    if (PyObject_GetBuffer(obj, view, PyBUF_FORMAT | PyBUF_C_CONTIGUOUS) != 0) return -1;
+    const char *f = view->format ? view->format : "";
+    if (*f == '=' || *f == '<' || *f == '@') f++;
+    if (view->itemsize == (Py_ssize_t)sizeof(double) && strcmp(f, "d") == 0) return 8;
+    if (view->itemsize == (Py_ssize_t)sizeof(float) && strcmp(f, "f") == 0) return 4;
+    PyBuffer_Release(view);
+    PyErr_Format(PyExc_TypeError, "%s must be a contiguous buffer of float64 or float32", what);
+    return -1;
+}
+
+/* the float32 entry points run on a plan kept between calls (sample_len and batch capacity) */
+static pthread_mutex_t f32_mutex = PTHREAD_MUTEX_INITIALIZER;
+static asx_plan *f32_plan;
+static size_t f32_plan_n, f32_plan_cap;
+
+/* with the GIL released */
+static int run_f32(const float *src, const float *smp, size_t n, size_t batch, int64_t *lag, double *coef, int32_t *ret)
+{
+    int rc = -1;
+    pthread_mutex_lock(&f32_mutex);
+    if (!f32_plan || f32_plan_n != n || f32_plan_cap < batch) {
+        if (f32_plan) asx_plan_destroy(f32_plan);
+        f32_plan = asx_plan_create(n, batch, -1);
+        f32_plan_n = n;
+        f32_plan_cap = batch;
+    }
+    if (f32_plan) rc = asx_xcorr_batch_f32(f32_plan, src, smp, batch, lag, coef, ret);
+    pthread_mutex_unlock(&f32_mutex);
+    return rc;
+}
+
 static PyObject *mod_cross_correlation(PyObject *self, PyObject *args)
 {
     UNUSED(self);
     PyObject *osrc, *osmp;
     if (!PyArg_ParseTuple(args, "OO", &osrc, &osmp)) return NULL;
     Py_buffer src, smp;
-    if (as_doubles(osrc, &src, "source") != 0) return NULL;
-    if (as_doubles(osmp, &smp, "sample") != 0) { PyBuffer_Release(&src); return NULL; }
-    const Py_ssize_t n = smp.len / (Py_ssize_t)sizeof(double);
+    const int ws = as_reals(osrc, &src, "source");
+    if (ws < 0) return NULL;
+    const int wt = as_reals(osmp, &smp, "sample");
+    if (wt < 0) { PyBuffer_Release(&src); return NULL; }
+    if (ws != wt) {
+        PyBuffer_Release(&src); PyBuffer_Release(&smp);
+        PyErr_SetString(PyExc_TypeError, "source and sample must have the same element type");
+        return NULL;
+    }
+    const Py_ssize_t n = smp.len / wt;
     if (n < 1 || src.len != 2 * smp.len) {
         PyBuffer_Release(&src); PyBuffer_Release(&smp);
         PyErr_SetString(PyExc_ValueError, "len(source) must be 2 * len(sample) and sample must not be empty");
@@ -125,11 +176,92 @@ static PyObject *mod_cross_correlation(PyObject *self, PyObject *args)
     long lag = 0;
     double coef = 0.0;
     int rc;
-    Py_BEGIN_ALLOW_THREADS
-    rc = cross_correlation((double *)src.buf, (double *)smp.buf, (size_t)n, &lag, &coef);
-    Py_END_ALLOW_THREADS
+    if (ws == 8) {
+        Py_BEGIN_ALLOW_THREADS
+        rc = cross_correlation((double *)src.buf, (double *)smp.buf, (size_t)n, &lag, &coef);
+        Py_END_ALLOW_THREADS
+    } else {
+        int64_t l64 = 0;
+        int32_t r32 = -1;
+        int call;
+        Py_BEGIN_ALLOW_THREADS
+        call = run_f32((const float *)src.buf, (const float *)smp.buf, (size_t)n, 1, &l64, &coef, &r32);
+        Py_END_ALLOW_THREADS
+        if (call != 0) {
+            PyBuffer_Release(&src); PyBuffer_Release(&smp);
+            PyErr_Format(PyExc_RuntimeError, "audiosync: %s", asx_last_error());
+            return NULL;
+        }
+        rc = r32;
+        lag = (long)l64;
+    }
     PyBuffer_Release(&src); PyBuffer_Release(&smp);
     return Py_BuildValue("ild", rc, lag, coef);
+}
+
+static PyObject *mod_cross_correlation_batch(PyObject *self, PyObject *args)
+{
+    UNUSED(self);
+    PyObject *osrc, *osmp;
+    Py_ssize_t batch_arg = -1;
+    if (!PyArg_ParseTuple(args, "OO|n", &osrc, &osmp, &batch_arg)) return NULL;
+    Py_buffer src, smp;
+    const int ws = as_reals(osrc, &src, "sources");
+    if (ws < 0) return NULL;
+    const int wt = as_reals(osmp, &smp, "samples");
+    if (wt < 0) { PyBuffer_Release(&src); return NULL; }
+    /* batch: leading dimension of a 2-D samples buffer, or the third argument for flat buffers */
+    Py_ssize_t batch = batch_arg;
+    if (batch < 0) batch = (smp.ndim >= 2 && smp.shape) ? smp.shape[0] : 1;
+    const Py_ssize_t total = smp.len / wt;
+    PyObject *result = NULL;
+    int64_t *lag = NULL;
+    double *coef = NULL;
+    int32_t *ret = NULL;
+    if (ws != wt) {
+        PyErr_SetString(PyExc_TypeError, "sources and samples must have the same element type");
+        goto done;
+    }
+    if (batch < 1 || total < batch || total % batch != 0 || src.len != 2 * smp.len) {
+        PyErr_SetString(PyExc_ValueError, "samples must hold batch * N values and sources batch * 2N");
+        goto done;
+    }
+    const size_t n = (size_t)(total / batch);
+    lag = malloc(sizeof(int64_t) * (size_t)batch);
+    coef = malloc(sizeof(double) * (size_t)batch);
+    ret = malloc(sizeof(int32_t) * (size_t)batch);
+    if (!lag || !coef || !ret) { PyErr_NoMemory(); goto done; }
+    int call = 0;
+    Py_BEGIN_ALLOW_THREADS
+    if (ws == 4) {
+        call = run_f32((const float *)src.buf, (const float *)smp.buf, n, (size_t)batch, lag, coef, ret);
+    } else {
+        for (Py_ssize_t b = 0; b < batch; b++) {
+            long l = 0;
+            coef[b] = 0.0;
+            ret[b] = cross_correlation((double *)src.buf + (size_t)b * 2 * n, (double *)smp.buf + (size_t)b * n, n, &l, &coef[b]);
+            lag[b] = l;
+        }
+    }
+    Py_END_ALLOW_THREADS
+    if (call != 0) {
+        PyErr_Format(PyExc_RuntimeError, "audiosync: %s", asx_last_error());
+        goto done;
+    }
+    PyObject *rets = PyList_New(batch), *lags = PyList_New(batch), *coefs = PyList_New(batch);
+    if (rets && lags && coefs) {
+        for (Py_ssize_t b = 0; b < batch; b++) {
+            PyList_SET_ITEM(rets, b, PyLong_FromLong(ret[b]));
+            PyList_SET_ITEM(lags, b, PyLong_FromLongLong((long long)lag[b]));
+            PyList_SET_ITEM(coefs, b, PyFloat_FromDouble(coef[b]));
+        }
+        result = PyTuple_Pack(3, rets, lags, coefs);
+    }
+    Py_XDECREF(rets); Py_XDECREF(lags); Py_XDECREF(coefs);
+done:
+    free(lag); free(coef); free(ret);
+    PyBuffer_Release(&src); PyBuffer_Release(&smp);
+    return result;
 }
 
 static PyObject *mod_set_feed(PyObject *self, PyObject *args)
@@ -170,7 +302,10 @@ static PyMethodDef methods[] = {
     { "get_debug", mod_get_debug, METH_NOARGS, "Debug logging on? Thread-safe." },
     { "set_debug", mod_set_debug, METH_VARARGS, "set_debug(flag). Thread-safe." },
     { "cross_correlation", mod_cross_correlation, METH_VARARGS,
-      "cross_correlation(source, sample) -> (ret, lag, coefficient) on the GPU; float64 buffers." },
+      "cross_correlation(source, sample) -> (ret, lag, coefficient) on the GPU; float64 or float32 buffers." },
+    { "cross_correlation_batch", mod_cross_correlation_batch, METH_VARARGS,
+      "cross_correlation_batch(sources, samples[, batch]) -> (rets, lags, coefficients); sources [B][2N], "
+      "samples [B][N], float32 (one batched launch) or float64 (the double ABI per pair)." },
     { "set_feed", mod_set_feed, METH_VARARGS,
       "set_feed(source, sample, frames_per_ms=0): the tracks run() will 'download' and 'record'." },
     { NULL, NULL, 0, NULL }

@@ -49,7 +49,38 @@ def test_cross_correlation_from_python(audiosync):
     with pytest.raises(ValueError):
         audiosync.cross_correlation(np.zeros(10), np.zeros(4))
     with pytest.raises(TypeError):
-        audiosync.cross_correlation(np.zeros(10, dtype=np.float32), np.zeros(5, dtype=np.float32))
+        audiosync.cross_correlation(np.zeros(10, dtype=np.int32), np.zeros(5, dtype=np.int32))
+    with pytest.raises(TypeError):
+        audiosync.cross_correlation(np.zeros(10, dtype=np.float64), np.zeros(5, dtype=np.float32))
+    # float32 buffers: the batched float32 path with one pair
+    ret32, lag32, coef32 = audiosync.cross_correlation(src, smp)
+    assert (ret32, lag32) == (o_ret, o_lag) and abs(coef32 - o_coef) < 1e-5
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_cross_correlation_batch_from_python(audiosync, dtype):
+    """the batched variant over the buffer protocol, against the oracle pair by pair"""
+    n, batch = 24000, 5
+    pairs = [oracle.synth_pair(78, p, n, 0) for p in range(batch)]
+    src = np.stack([p[0] for p in pairs]).astype(dtype)
+    smp = np.stack([p[1] for p in pairs]).astype(dtype)
+    smp[3] = 0                                     # one all-zero sample: ret -1, NaN coefficient
+    rets, lags, coefs = audiosync.cross_correlation_batch(src, smp)
+    assert len(rets) == len(lags) == len(coefs) == batch
+    for b in range(batch):
+        o_ret, o_lag, o_coef = oracle.cross_correlation(src[b], smp[b])
+        assert (rets[b], lags[b]) == (o_ret, o_lag), b
+        if o_ret == 0:
+            assert abs(coefs[b] - o_coef) < 1e-5
+        else:
+            assert coefs[b] != coefs[b]
+    # flat buffers with an explicit batch, and the shape errors
+    r2, l2, c2 = audiosync.cross_correlation_batch(src.reshape(-1), smp.reshape(-1), batch)
+    assert l2 == lags
+    with pytest.raises(ValueError):
+        audiosync.cross_correlation_batch(src.reshape(-1), smp.reshape(-1), 7)
+    with pytest.raises(ValueError):
+        audiosync.cross_correlation_batch(src[:, :-2].copy(), smp)
 
 
 def test_run_pause_resume_abort_state_machine(audiosync):

@@ -318,6 +318,74 @@ def test_stream_growing_window_matches_oracle(mod):
     st.close()
 
 
+def test_stream_all_six_intervals_match_oracle(mod):
+    """BASELINE config 5 at full length: the reference's interval table 3/6/10/15/20/30 s
+    (src/audiosync.c:50-57) on prefixes of one 30 s pair, frames appended incrementally as f64le doubles
+    (src/audiosync.c:226-259); at EVERY prefix the lag equals the oracle's and the coefficient is within 1e-5."""
+    sr = 48000
+    n_max = 30 * sr
+    rng = np.random.default_rng(2025)
+    true_lag = 31337
+    base = rng.uniform(-1, 1, 2 * n_max + true_lag).astype(np.float32)
+    src = base[: 2 * n_max].astype(np.float64)
+    smp = (0.5 * base[true_lag: true_lag + n_max] + 0.3 * rng.uniform(-1, 1, n_max)).astype(np.float32).astype(np.float64)
+    st = mod.Stream(n_max, 0)
+    up_s = up_t = 0
+    for seconds in (3, 6, 10, 15, 20, 30):
+        n = seconds * sr
+        st.append(src[up_s: 2 * n], smp[up_t: n])
+        up_s, up_t = 2 * n, n
+        ret, lag, coef = st.xcorr(n)
+        o_ret, o_lag, o_coef = oracle.cross_correlation(src[: 2 * n], smp[:n])
+        assert (ret, lag) == (o_ret, o_lag) == (0, true_lag), (seconds, lag, o_lag)
+        assert abs(coef - o_coef) < COEF_TOL, (seconds, coef, o_coef)
+    st.close()
+
+
+def test_config4_full_batch_on_one_gpu_recovers_every_planted_delay(mod, torch):
+    """BASELINE configs[3] at its full size on ONE GPU: 8192 pairs of N = 480 000 generated on the device
+    (47 GB of float32 inputs, resident), processed in launch groups; every planted delay comes back."""
+    n, batch = 480000, 8192
+    d_src = torch.empty(batch * 2 * n, dtype=torch.float32, device="cuda")
+    d_smp = torch.empty(batch * n, dtype=torch.float32, device="cuda")
+    d_true = torch.empty(batch, dtype=torch.int64, device="cuda")
+    d_lag = torch.zeros(batch, dtype=torch.int64, device="cuda")
+    d_coef = torch.zeros(batch, dtype=torch.float64, device="cuda")
+    d_ret = torch.full((batch,), 7, dtype=torch.int32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    mod.synth_pairs_dev(4, 0, batch, n, 0, d_src.data_ptr(), d_smp.data_ptr(), d_true.data_ptr(), stream)
+    torch.cuda.synchronize()
+    with mod.Plan(n, batch, 0) as plan:
+        assert plan.group < batch                      # really chunked
+        plan.xcorr_batch_dev(d_src.data_ptr(), d_smp.data_ptr(), batch, d_lag.data_ptr(), d_coef.data_ptr(),
+                             d_ret.data_ptr(), 0)
+        plan.sync()
+        assert plan.peak_overflows() == 0
+    assert bool(torch.equal(d_lag, d_true)) and int(d_ret.abs().sum()) == 0
+    assert float(d_coef.min()) > 0.3
+    # spot-check three pairs of the batch against the oracle (first, a group boundary, last)
+    for p in (0, 372, batch - 1):
+        s, t, l = oracle.synth_pair(4, p, n, 0)
+        o_ret, o_lag, o_coef = oracle.cross_correlation(s, t)
+        assert (o_ret, o_lag) == (0, int(d_lag[p])) and abs(float(d_coef[p]) - o_coef) < COEF_TOL
+    del d_src, d_smp
+    torch.cuda.empty_cache()
+
+
+def test_multi_plan_entry_point_partitions_and_orders_results(mod):
+    """asx_xcorr_batch_multi: three plans (here all on device 0; one per GPU on a node), an uneven batch of 8"""
+    n, batch = 6000, 8
+    pairs = [oracle.synth_pair(41, p, n, 1) for p in range(batch)]
+    src = np.stack([p[0] for p in pairs]); smp = np.stack([p[1] for p in pairs])
+    plans = [mod.Plan(n, 3, 0) for _ in range(3)]
+    lag, coef, ret = mod.xcorr_batch_multi(plans, src, smp)
+    for p in plans:
+        p.close()
+    for i in range(batch):
+        o_ret, o_lag, o_coef = oracle.cross_correlation(src[i], smp[i])
+        assert (int(ret[i]), int(lag[i])) == (o_ret, o_lag) and abs(float(coef[i]) - o_coef) < COEF_TOL
+
+
 # ---- more edge cases -------------------------------------------------------------------------
 
 @pytest.mark.parametrize("n", [1, 2, 3, 4, 9, 3645])
