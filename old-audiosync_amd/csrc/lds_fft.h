@@ -408,9 +408,15 @@ template <int R> __device__ __forceinline__ void stage_twiddles_from(float2 w1, 
     });
 }
 
-template <int R, bool INV, bool GFAST, bool UNIT_TW>
+// Sink: what happens to a butterfly's R outputs.  NoSink = written back to their slots (in place).
+// Any other type is called as sink(std::integral_constant<int, R>{}, v, g, pos0, q): v[T] is element
+// pos0 + T*q of transform pair g -- the outputs stay in registers and LDS keeps the stage's INPUT (the
+// peak search of k_inv_cols consumes the last inverse stage this way: r never reaches LDS either).
+struct NoSink {};
+
+template <int R, bool INV, bool GFAST, bool UNIT_TW, class Sink = NoSink>
 __device__ __forceinline__ void lds_stage(float4 *lds, const StageK K, const LdsLayout &L,
-                                          const float2 *__restrict__ tw, TwPre pre)
+                                          const float2 *__restrict__ tw, TwPre pre, Sink &&sink = Sink{})
 {
     const int ns = K.ns, q = K.q, nbf = K.nbf, twmul = K.twmul;
     const float inv_q = K.inv_q, inv_nbf = K.inv_nbf;
@@ -450,28 +456,31 @@ __device__ __forceinline__ void lds_stage(float4 *lds, const StageK K, const Lds
                 Bfly<R, true>::run(v);
             }
         }
-        static_for<0, R>([&](auto T) __attribute__((always_inline)) { lds_put(p + T * step, v[T]); });
+        if constexpr (std::is_same<typename std::decay<Sink>::type, NoSink>::value)
+            static_for<0, R>([&](auto T) __attribute__((always_inline)) { lds_put(p + T * step, v[T]); });
+        else
+            sink(std::integral_constant<int, R>{}, v, g, b * ns + j, q);
     }
 }
 
-template <int R, bool INV, bool GFAST>
+template <int R, bool INV, bool GFAST, class Sink = NoSink>
 __device__ __forceinline__ void lds_stage_r(float4 *lds, const StageK K, const LdsLayout &L,
-                                            const float2 *__restrict__ tw, TwPre pre)
+                                            const float2 *__restrict__ tw, TwPre pre, Sink &&sink = Sink{})
 {
     if (K.q == 1) // wave-uniform
-        lds_stage<R, INV, GFAST, true>(lds, K, L, tw, pre);
+        lds_stage<R, INV, GFAST, true>(lds, K, L, tw, pre, sink);
     else
-        lds_stage<R, INV, GFAST, false>(lds, K, L, tw, pre);
+        lds_stage<R, INV, GFAST, false>(lds, K, L, tw, pre, sink);
 }
 
 // MAXR: largest radix this kernel variant carries code for.  Register allocation is per
 // kernel, so a variant without the radix-15/16 bodies keeps the occupancy of the small ones.
-template <int MAXR, bool INV, bool GFAST>
+template <int MAXR, bool INV, bool GFAST, class Sink = NoSink>
 __device__ __forceinline__ void lds_stage_any(float4 *lds, const StageK K, const LdsLayout &L,
-                                              const float2 *__restrict__ tw, TwPre pre)
+                                              const float2 *__restrict__ tw, TwPre pre, Sink &&sink = Sink{})
 {
 #define ASX_STAGE_CASE(R) \
-    case R: if constexpr (R <= MAXR) lds_stage_r<R, INV, GFAST>(lds, K, L, tw, pre); break;
+    case R: if constexpr (R <= MAXR) lds_stage_r<R, INV, GFAST>(lds, K, L, tw, pre, sink); break;
     switch (K.R) { // wave-uniform
         ASX_STAGE_CASE(16)
         ASX_STAGE_CASE(15)
@@ -483,7 +492,7 @@ __device__ __forceinline__ void lds_stage_any(float4 *lds, const StageK K, const
         ASX_STAGE_CASE(5)
         ASX_STAGE_CASE(4)
         ASX_STAGE_CASE(3)
-    default: lds_stage_r<2, INV, GFAST>(lds, K, L, tw, pre); break;
+    default: lds_stage_r<2, INV, GFAST>(lds, K, L, tw, pre, sink); break;
     }
 #undef ASX_STAGE_CASE
 }
@@ -528,4 +537,69 @@ __device__ __forceinline__ void lds_fft_static(float4 *lds, const LdsLayout &L, 
         pre = next;
         __syncthreads();
     });
+}
+
+// ---- transforms whose LAST stage is consumed from registers (Sink) -------------------------------
+// lds_fft*_head runs every stage but the last one to execute (stage 0 of an inverse, stage nstages-1
+// of a forward transform) and returns the twiddle prefetch of that last stage; the caller then runs
+// lds_last_stage*(..., sink) as often as it likes: the stage reads LDS and writes nothing.
+template <int MAXR, bool INV, bool GFAST>
+__device__ __forceinline__ TwPre lds_fft_head(float4 *lds, const AsxStages &st, const LdsLayout &L,
+                                              const float2 *__restrict__ tw, TwPre pre)
+{
+    if (!INV) {
+        for (int i = 0; i < st.nstages - 1; i++) {
+            const TwPre next = tw_prefetch<GFAST>(st, i + 1, L, tw);
+            lds_stage_any<MAXR, false, GFAST>(lds, stage_k(st, i), L, tw, pre);
+            pre = next;
+            __syncthreads();
+        }
+    } else {
+        for (int i = st.nstages - 1; i >= 1; i--) {
+            const TwPre next = tw_prefetch<GFAST>(st, i - 1, L, tw);
+            lds_stage_any<MAXR, true, GFAST>(lds, stage_k(st, i), L, tw, pre);
+            pre = next;
+            __syncthreads();
+        }
+    }
+    return pre;
+}
+template <int MAXR, bool INV, bool GFAST, class Sink>
+__device__ __forceinline__ void lds_last_stage(float4 *lds, const AsxStages &st, const LdsLayout &L,
+                                               const float2 *__restrict__ tw, TwPre pre, Sink &&sink)
+{
+    if (st.nstages < 1) {
+        // a one-point transform (M1 = 1): the tile itself is the result
+        for (int w = threadIdx.x; w < L.ngroups * st.n; w += L.nthreads) {
+            int g, e;
+            if (GFAST) { g = w & (L.ngroups - 1); e = w >> L.log_ngroups; }
+            else { g = w / st.n; e = w - g * st.n; }
+            Cx2 v[1] = { lds_get(lds + g * L.group_stride + e * L.elem_stride) };
+            sink(std::integral_constant<int, 1>{}, v, g, e, 1);
+        }
+        return;
+    }
+    lds_stage_any<MAXR, INV, GFAST>(lds, stage_k(st, INV ? 0 : st.nstages - 1), L, tw, pre, sink);
+}
+
+template <class S, bool INV, bool GFAST>
+__device__ __forceinline__ TwPre lds_fft_static_head(float4 *lds, const LdsLayout &L, const float2 *__restrict__ tw, TwPre pre)
+{
+    static_for<0, S::nstages - 1>([&](auto I) __attribute__((always_inline)) {
+        constexpr int i = INV ? S::nstages - 1 - decltype(I)::value : decltype(I)::value;
+        constexpr int inext = INV ? i - 1 : i + 1;
+        constexpr StageK K = S::stage(i);
+        const TwPre next = tw_prefetch_k<GFAST>(S::stage(inext), L, tw);
+        lds_stage<K.R, INV, GFAST, K.q == 1>(lds, K, L, tw, pre);
+        pre = next;
+        __syncthreads();
+    });
+    return pre;
+}
+template <class S, bool INV, bool GFAST, class Sink>
+__device__ __forceinline__ void lds_last_stage_static(float4 *lds, const LdsLayout &L, const float2 *__restrict__ tw, TwPre pre,
+                                                      Sink &&sink)
+{
+    constexpr StageK K = S::stage(INV ? 0 : S::nstages - 1);
+    lds_stage<K.R, INV, GFAST, K.q == 1>(lds, K, L, tw, pre, sink);
 }

@@ -716,8 +716,11 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_inv_cols(const AsxDe
     }
     __syncthreads();
     ASX_STAMP_AT(2, stamp_block, 1);
-    if constexpr (STATIC) lds_fft_static<S1, true, true>(lds4, Lc, P.tw1, pre);
-    else lds_fft<MAXR, true, true>(lds4, PD.st1, Lc, P.tw1, pre);
+    // every inverse stage but the last: the last one's outputs are consumed from registers below
+    // (r reaches neither HBM nor LDS; LDS keeps that stage's input, so the stage can be run again)
+    TwPre pre_last;
+    if constexpr (STATIC) pre_last = lds_fft_static_head<S1, true, true>(lds4, Lc, P.tw1, pre);
+    else pre_last = lds_fft_head<MAXR, true, true>(lds4, PD.st1, Lc, P.tw1, pre);
     ASX_STAMP_AT(2, stamp_block, 2);
 
     // The pair's running maximum so far (other tiles publish theirs with atomicMax below) and the width
@@ -726,46 +729,57 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_inv_cols(const AsxDe
     // candidates (k_finalize filters them against the final maximum).
     const asx_peak_t run0 = W.pairmax[pair];
     const float b2 = W.bound2[pair];
-    // Peak search.  A thread meets its lags in increasing order, so a strict '>' keeps the
-    // earliest of equal keys, like the reference's sequential scan (src/cross_correlation.c:60).
-    // Fast path (block-uniform): the tile is full, every lag counts, lag 0 (the signed one) is
-    // not in it and r is not being dumped -> two packed max per slot, indices resolved at the end.
-    const bool fast = even && (c0 + T <= M2) && (P.nout == P.F) && (tile != 0) && (r_out == nullptr);
-    // one candidate test per lag of a slot (second look below)
-    auto examine_slot = [&](int e, float4 g, float thr) {
-        const int cg = e & (H - 1), j1 = e >> logH;
-        const int j2 = c0 + 2 * cg;
-        if (j2 >= M2) return;
-        const uint32_t i0 = 2u * ((uint32_t)j1 * (uint32_t)M2 + (uint32_t)j2);
-        const float val[4] = { g.x, g.y, g.z, g.w }; // slot = {re0, im0, re1, im1}: four consecutive lags
-#pragma unroll
-        for (int h = 0; h < 4; h++) {
-            const uint32_t idx = i0 + h;
-            if (idx < P.nout && j2 + (h >> 1) < M2) {
-                const float key = peak_key_of(val[h], idx);
-                if (key >= thr) cand_append(W, pair, idx, key);
-            }
-        }
+    auto last_stage = [&](auto &&sink) __attribute__((always_inline)) {
+        if constexpr (STATIC) lds_last_stage_static<S1, true, true>(lds4, Lc, P.tw1, pre_last, sink);
+        else lds_last_stage<MAXR, true, true>(lds4, PD.st1, Lc, P.tw1, pre_last, sink);
     };
+    // Output T of a butterfly is row j1 = pos0 + T*q of column pair g: four consecutive lags
+    // {re0, im0, re1, im1} from i0 = 2*(j1*M2 + c0 + 2g).
+    // Peak search (src/cross_correlation.c:52-67): largest key, smallest lag among equal keys.
+    // Fast path (block-uniform): the tile is full, every lag counts, lag 0 (the signed one) is
+    // not in it and r is not being dumped -> one packed maximum per slot, indices resolved at the end.
+    const bool fast = even && (c0 + T <= M2) && (P.nout == P.F) && (tile != 0) && (r_out == nullptr);
+    // second look (rare, one instantiation for both paths): the thread runs its last stage again and
+    // appends every valid lag whose key is inside the window
+    auto examine_again = [&](float thr) __attribute__((always_inline)) {
+        last_stage([&](auto RC, auto &v, int g, int pos0, int q) __attribute__((always_inline)) {
+            const int j2 = c0 + 2 * g;
+            if (j2 >= M2) return;
+            static_for<0, decltype(RC)::value>([&](auto TT) __attribute__((always_inline)) {
+                constexpr int t = decltype(TT)::value;
+                const float val[4] = { v[t].re.x, v[t].im.x, v[t].re.y, v[t].im.y };
+                const uint32_t i0 = 2u * ((uint32_t)(pos0 + t * q) * (uint32_t)M2 + (uint32_t)j2);
+#pragma unroll
+                for (int h = 0; h < 4; h++) {
+                    const uint32_t idx = i0 + h;
+                    if (idx < P.nout && j2 + (h >> 1) < M2) {
+                        const float key = peak_key_of(val[h], idx);
+                        if (key >= thr) cand_append(W, pair, idx, key);
+                    }
+                }
+            });
+        });
+    };
+    float thr_again = 0.f;
+    bool again = false;
     if (fast) {
         // pass 1: per thread the largest and second largest slot maximum
         float best_m = -INFINITY, second_m = -INFINITY;
-        int best_e = threadIdx.x;
-        for (int e = threadIdx.x; e < nelem4; e += nthreads) {
-            const float4 g = lds4[e];
-            const float m = fmaxf(fmaxf(fabsf(g.x), fabsf(g.y)), fmaxf(fabsf(g.z), fabsf(g.w))); // NaNs drop out
-            if (m > best_m) { second_m = best_m; best_m = m; best_e = e; }
-            else if (m > second_m) second_m = m;
-        }
-        const float4 gb = lds4[best_e];
-        uint32_t my_idx;
-        {
-            const int cg = best_e & (H - 1), j1 = best_e >> logH;
-            const uint32_t i0 = 2u * ((uint32_t)j1 * (uint32_t)M2 + (uint32_t)(c0 + 2 * cg));
-            // lag order inside a slot = its memory order {re0, im0, re1, im1}
-            const uint32_t h = fabsf(gb.x) == best_m ? 0u : fabsf(gb.y) == best_m ? 1u : fabsf(gb.z) == best_m ? 2u : 3u;
-            my_idx = i0 + h;
-        }
+        uint32_t best_i0 = 0xFFFFFFFFu;
+        float4 gb = make_float4(0.f, 0.f, 0.f, 0.f);
+        last_stage([&](auto RC, auto &v, int g, int pos0, int q) __attribute__((always_inline)) {
+            static_for<0, decltype(RC)::value>([&](auto TT) __attribute__((always_inline)) {
+                constexpr int t = decltype(TT)::value;
+                const float4 s4 = make_float4(v[t].re.x, v[t].im.x, v[t].re.y, v[t].im.y);
+                const float m = fmaxf(fmaxf(fabsf(s4.x), fabsf(s4.y)), fmaxf(fabsf(s4.z), fabsf(s4.w))); // NaNs drop out
+                const uint32_t i0 = 2u * ((uint32_t)(pos0 + t * q) * (uint32_t)M2 + (uint32_t)(c0 + 2 * g));
+                if (m > best_m || (m == best_m && i0 < best_i0)) { second_m = best_m; best_m = m; gb = s4; best_i0 = i0; }
+                else if (m > second_m) second_m = m;
+            });
+        });
+        // lag order inside a slot = its memory order {re0, im0, re1, im1}
+        const uint32_t hh = fabsf(gb.x) == best_m ? 0u : fabsf(gb.y) == best_m ? 1u : fabsf(gb.z) == best_m ? 2u : 3u;
+        const uint32_t my_idx = best_i0 + hh;
         // wave maximum in registers, smallest lag among the lanes that hold it, one entry per wave
         const float wmax = wave_max_nonneg(fmaxf(best_m, 0.f));
         unsigned long long holders = __ballot(best_m == wmax);
@@ -782,51 +796,52 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_inv_cols(const AsxDe
         asx_peak_t tb = red[0];
         for (int w = 1; w < (int)((nthreads + 63) >> 6); w++) tb = peak_max(tb, red[w]);
         if (threadIdx.x == 0) atomicMax(&W.pairmax[pair], tb);
-        // second look at the tile (still in LDS): lags within the float32 error window of the largest
-        // key known so far.  Almost every thread is below the threshold; the one that holds the maximum
-        // usually has no second slot near it and examines just that slot.
+        // Second look: lags within the float32 error window of the largest key known so far.  Almost every
+        // thread is below the threshold; the one that holds the maximum usually has no second slot near
+        // it and examines just that slot; a thread with more runs its last stage again.
         const float thr = near_max_threshold(peak_key(peak_max(tb, run0)), b2);
+        thr_again = thr;
         if (best_m >= thr) {
             if (second_m >= thr) {
-                for (int e = threadIdx.x; e < nelem4; e += nthreads) {
-                    const float4 g = lds4[e];
-                    const float m = fmaxf(fmaxf(fabsf(g.x), fabsf(g.y)), fmaxf(fabsf(g.z), fabsf(g.w)));
-                    if (m >= thr) examine_slot(e, g, thr);
-                }
+                again = true;
             } else {
-                examine_slot(best_e, gb, thr);
+                const float val[4] = { gb.x, gb.y, gb.z, gb.w };
+#pragma unroll
+                for (int h = 0; h < 4; h++)
+                    if (fabsf(val[h]) >= thr) cand_append(W, pair, best_i0 + h, fabsf(val[h]));
             }
         }
     } else {
-        asx_peak_t best = 0;
+        // general form: first tile (lag 0 competes signed), ragged or embedded tiles, r dumped for tests
         float best_key = -INFINITY;
         uint32_t best_idx = 0xFFFFFFFFu;
-        for (int e = threadIdx.x; e < nelem4; e += nthreads) {
-            const int cg = e & (H - 1), j1 = e >> logH;
-            const int j2 = c0 + 2 * cg;
-            if (j2 < M2) {
-                const uint32_t i0 = 2u * ((uint32_t)j1 * (uint32_t)M2 + (uint32_t)j2);
-                const float4 g = lds4[e];
-                const float val[4] = { g.x, g.y, g.z, g.w }; // slot = {re0, im0, re1, im1}: four consecutive lags
+        last_stage([&](auto RC, auto &v, int g, int pos0, int q) __attribute__((always_inline)) {
+            const int j2 = c0 + 2 * g;
+            if (j2 >= M2) return;
+            static_for<0, decltype(RC)::value>([&](auto TT) __attribute__((always_inline)) {
+                constexpr int t = decltype(TT)::value;
+                const float val[4] = { v[t].re.x, v[t].im.x, v[t].re.y, v[t].im.y };
+                const uint32_t i0 = 2u * ((uint32_t)(pos0 + t * q) * (uint32_t)M2 + (uint32_t)j2);
 #pragma unroll
                 for (int h = 0; h < 4; h++) {
                     const uint32_t idx = i0 + h;
                     if (idx < P.nout && j2 + (h >> 1) < M2) {
                         const float key = peak_key_of(val[h], idx);
-                        if (key > best_key) { best_key = key; best_idx = idx; }
+                        if (key > best_key || (key == best_key && idx < best_idx) || best_idx == 0xFFFFFFFFu) { best_key = key; best_idx = idx; }
                         if (r_out) r_out[pair * (size_t)P.nout + idx] = val[h];
                     }
                 }
-            }
-        }
-        best = best_idx == 0xFFFFFFFFu ? 0 : peak_pack_key(best_key, best_idx);
+            });
+        });
+        asx_peak_t best = best_idx == 0xFFFFFFFFu ? 0 : peak_pack_key(best_key, best_idx);
         best = block_peak_max(best, red);
         if (threadIdx.x == 0) { atomicMax(&W.pairmax[pair], best); red[0] = best; }
         __syncthreads();
-        // second look at the tile (still in LDS), as above
         const float thr = near_max_threshold(peak_key(peak_max(red[0], run0)), b2);
-        for (int e = threadIdx.x; e < nelem4; e += nthreads) examine_slot(e, lds4[e], thr);
+        again = best_key >= thr;
+        thr_again = thr;
     }
+    if (again) examine_again(thr_again);
     ASX_STAMP_AT(2, stamp_block, 3);
 }
 

@@ -8,7 +8,7 @@ cp $R/old-audiosync_amd/libaudiosync_hip.so /tmp/asx_keep.so
 for r in $(seq $rounds); do
   for l in "${libs[@]}"; do
     cp $R/ab/$l.so $R/old-audiosync_amd/libaudiosync_hip.so
-    echo -n "$l: "; python3 $R/bench.py --no-cpu "$@" | python3 $R/tools/brief.py
+    echo -n "$l: "; python3 $R/bench.py --no-cpu --no-config4 --no-single "$@" | python3 $R/tools/brief.py
   done
 done
 cp /tmp/asx_keep.so $R/old-audiosync_amd/libaudiosync_hip.so

@@ -2,9 +2,9 @@
 # usage: tools/pmc.sh <outdir> <bench args...>   (run on the GPU box via gpurun)
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/$1; shift
 mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
-rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY --output-format csv -d $OUT/sq1 -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu "$@" > $OUT/sq1.log 2>&1
-rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/sq2 -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu "$@" > $OUT/sq2.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu "$@" > $OUT/trace.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY --output-format csv -d $OUT/sq1 -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu --no-config4 --no-single "$@" > $OUT/sq1.log 2>&1
+rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/sq2 -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu --no-config4 --no-single "$@" > $OUT/sq2.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu --no-config4 --no-single "$@" > $OUT/trace.log 2>&1
 python3 - $OUT <<'PY'
 import csv, collections, glob, sys
 out=sys.argv[1]

@@ -2,7 +2,7 @@
 # usage: tools/pmc_any.sh <outdir> "<counters>" [bench args]  -> per-kernel average of each counter
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/$1; CTRS=$2; shift; shift
 mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
-rocprofv3 --pmc $CTRS --output-format csv -d $OUT/p -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu "$@" > $OUT/p.log 2>&1
+rocprofv3 --pmc $CTRS --output-format csv -d $OUT/p -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu --no-config4 --no-single "$@" > $OUT/p.log 2>&1
 python3 - $OUT <<'PY'
 import csv, collections, glob, sys
 out=sys.argv[1]

@@ -5,9 +5,9 @@
 # FETCH_SIZE doubled (gfx950 tallies 128-B requests at 64 B), units KiB.
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/$1; shift
 mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu "$@" > $OUT/fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu "$@" > $OUT/write.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu "$@" > $OUT/trace.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu --no-config4 --no-single "$@" > $OUT/fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu --no-config4 --no-single "$@" > $OUT/write.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu --no-config4 --no-single "$@" > $OUT/trace.log 2>&1
 python3 - $OUT <<'PY'
 import csv, collections, glob, json, sys
 out=sys.argv[1]
