@@ -162,7 +162,7 @@ static int plan_init(asx_plan *p, size_t N, size_t max_batch, const char *split)
     d.threads_rows = asx_pick_threads(h.st2, 2, (h.M2 + ASX_ROW_STEPS - 1) / ASX_ROW_STEPS, asx_lds_bytes_rows(d));
     if (const char *e = getenv("ASX_THREADS_COLS")) d.threads_cols = atoi(e);
     if (const char *e = getenv("ASX_THREADS_ROWS")) d.threads_rows = atoi(e);
-    if (dev_upload(p, &d.tw1, h.tw1) || dev_upload(p, &d.tw2, h.tw2) || dev_upload(p, &d.tw_lo, h.tw_lo) ||
+    if (dev_upload(p, &d.tw1, h.tw1) || dev_upload(p, &d.tw2, h.tw2) || dev_upload(p, &d.tw2s, h.tw2s) || dev_upload(p, &d.tw_lo, h.tw_lo) ||
         dev_upload(p, &d.tw_hi, h.tw_hi) ||
         dev_upload(p, &d.k1_of_pos1, h.k1_of_pos1) || dev_upload(p, &d.pos1_of_k1, h.pos1_of_k1) ||
         dev_upload(p, &d.pos2_of_k2, h.pos2_of_k2) || dev_upload(p, &d.row_tasks, h.row_tasks))

@@ -64,6 +64,7 @@ struct AsxDev {
     AsxStages st1, st2;    // schedules for length M1 and M2
     const float2 *tw1;     // w_{M1}^q, q < M1
     const float2 *tw2;     // w_{M2}^q, q < M2
+    const float2 *tw2s;    // the same in slot order: tw2s[pos2_of_k2[k2]] = w_{M2}^k2
     const float2 *tw_lo;   // w_F^q, q < 2^ASX_TW_LOG
     const float2 *tw_hi;   // w_F^(h * 2^ASX_TW_LOG)
     const int *k1_of_pos1; // row slot -> k1

@@ -262,6 +262,14 @@ std::string asx_host_plan_build(size_t N, const char *split_override, AsxHostPla
     hp->k1_of_pos1.assign(M1, 0);
     for (int k = 0; k < M1; k++) hp->k1_of_pos1[hp->pos1_of_k1[k]] = k;
     hp->pos2_of_k2 = asx_position_table(hp->st2);
+    // w_M2^k2 in SLOT order (tw2s[pos2_of_k2[k2]] = w_M2^k2): the spectral combine of k_rows walks a row
+    // slot by slot.  It relies on digit reversal mapping k2 -> M2-1-k2 to slot -> M2-1-slot (all digits
+    // complemented); checked here so that a different position table cannot silently break it.
+    hp->tw2s.resize(M2);
+    for (int k2 = 0; k2 < M2; k2++) {
+        if (hp->pos2_of_k2[M2 - 1 - k2] != M2 - 1 - hp->pos2_of_k2[k2]) return "position table is not a digit reversal";
+        hp->tw2s[hp->pos2_of_k2[k2]] = hp->tw2[k2];
+    }
     hp->row_tasks.resize(M1 / 2 + 1);
     for (int k1 = 0; k1 <= M1 / 2; k1++) {
         const int m1 = (M1 - k1) % M1;

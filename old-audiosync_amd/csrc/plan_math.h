@@ -14,7 +14,7 @@ struct AsxHostPlan {
     uint32_t F = 0, M = 0, src_valid = 0;
     int M1 = 0, M2 = 0, T = 0, logT = 0, ntiles = 0;
     AsxStages st1{}, st2{};
-    std::vector<float2> tw1, tw2, tw_lo, tw_hi;
+    std::vector<float2> tw1, tw2, tw2s, tw_lo, tw_hi;
     std::vector<int> k1_of_pos1, pos1_of_k1, pos2_of_k2;
     std::vector<int4> row_tasks;
 };

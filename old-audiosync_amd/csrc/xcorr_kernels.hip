@@ -47,7 +47,7 @@ extern __shared__ __attribute__((aligned(16))) float2 asx_lds[];
 // scalar load plus a wait that also drains the LDS queue (the spectral combine of k_rows alone
 // re-read two pointers in each of its five steps).
 struct AsxKP {
-    const float2 *tw1, *tw2, *tw_lo, *tw_hi;
+    const float2 *tw1, *tw2, *tw2s, *tw_lo, *tw_hi;
     const int *pos2_of_k2;
     uint32_t N, F, M, nout, src_valid, src_period;
     int M1, M2, T, logT, ntiles;
@@ -57,7 +57,7 @@ struct AsxKP {
 __device__ __forceinline__ AsxKP asx_kp(const AsxDev &D)
 {
     AsxKP k;
-    k.tw1 = D.tw1; k.tw2 = D.tw2; k.tw_lo = D.tw_lo; k.tw_hi = D.tw_hi;
+    k.tw1 = D.tw1; k.tw2 = D.tw2; k.tw2s = D.tw2s; k.tw_lo = D.tw_lo; k.tw_hi = D.tw_hi;
     k.pos2_of_k2 = D.pos2_of_k2;
     k.N = D.N; k.F = D.F; k.M = D.M; k.nout = D.nout; k.src_valid = D.src_valid; k.src_period = D.src_period;
     k.M1 = D.M1; k.M2 = D.M2; k.T = D.T; k.logT = D.logT; k.ntiles = D.ntiles;
@@ -338,7 +338,11 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, ASX_ROWS_MIN_WAVES) void k_row
         RowRegs L;
         RowRegsWide LW;
         {
+#ifdef ASX_EXP_PAIR0 /* experiment: all traffic of the kernel falls on pair 0's rows (Infinity-Cache resident) */
+            const float2 *gx = zxa, *gy = zya;
+#else
             const float2 *gx = zxa + (size_t)pair * M, *gy = zya + (size_t)pair * M;
+#endif
             if (wide) {
                 static_for<0, ASX_ROW_WSTEPS>([&](auto I) __attribute__((always_inline)) {
                     const int q = threadIdx.x + decltype(I)::value * nthreads;
@@ -430,17 +434,20 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, ASX_ROWS_MIN_WAVES) void k_row
         float2 gk[ASX_ROW_STEPS], gm[ASX_ROW_STEPS];
         int sa[ASX_ROW_STEPS], sb[ASX_ROW_STEPS]; // -1: nothing to write
         if (!self) {
-            // The common case, written as three sweeps over the thread's bins so that the table
-            // reads of all of them are in flight together, then the LDS reads, then the arithmetic
-            // (step by step, each bin would wait for its own table read and its own LDS read).
+            // The common case.  A thread walks SLOTS s = t + i*nthreads, not bins: consecutive lanes read
+            // consecutive slots of A and (digit reversal complements every digit: the partner bin
+            // M2-1-k2 sits at slot M2-1-s) consecutive slots of B, backwards -- no bank conflicts, no
+            // index table; the twiddle table is kept in slot order for this.  Three sweeps so that the
+            // table reads of all of a thread's slots are in flight together, then the LDS reads, then the
+            // arithmetic (slot by slot, each would wait for its own table read and its own LDS read).
             float2 w2[ASX_ROW_STEPS];
             static_for<0, ASX_ROW_STEPS>([&](auto I) __attribute__((always_inline)) {
                 constexpr int i = decltype(I)::value;
-                const int k2 = threadIdx.x + i * nthreads;
-                const int kc = k2 < M2 ? k2 : 0; // clamped: the loads are unconditional
-                sa[i] = P.pos2_of_k2[kc];
-                sb[i] = P.pos2_of_k2[M2 - 1 - kc];
-                w2[i] = P.tw2[kc];
+                const int s = threadIdx.x + i * nthreads;
+                const int sc = s < M2 ? s : 0; // clamped: the loads are unconditional
+                sa[i] = sc;
+                sb[i] = M2 - 1 - sc;
+                w2[i] = P.tw2s[sc];
             });
             Cx2 za[ASX_ROW_STEPS], zb[ASX_ROW_STEPS];
             static_for<0, ASX_ROW_STEPS>([&](auto I) __attribute__((always_inline)) {
@@ -450,9 +457,9 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, ASX_ROWS_MIN_WAVES) void k_row
             });
             static_for<0, ASX_ROW_STEPS>([&](auto I) __attribute__((always_inline)) {
                 constexpr int i = decltype(I)::value;
-                const int k2 = threadIdx.x + i * nthreads;
+                const int s = threadIdx.x + i * nthreads;
                 combine_pair(za[i], zb[i], cmul(wA, w2[i]), gk[i], gm[i]);
-                if (k2 >= M2) sa[i] = -1;
+                if (s >= M2) sa[i] = -1;
             });
         } else {
         static_for<0, ASX_ROW_STEPS>([&](auto I) __attribute__((always_inline)) {
@@ -514,7 +521,11 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, ASX_ROWS_MIN_WAVES) void k_row
         // that the LDS reads of all steps are in flight together (a rolled loop pays the LDS latency
         // once per step).  twa / twb ride in registers from the load phase.  Even rows leave as 16
         // bytes per lane, like they came.
+#ifdef ASX_EXP_PAIR0
+        float2 *go = ga;
+#else
         float2 *go = ga + (size_t)pair * M;
+#endif
         if (wide) {
             Cx2 g0[ASX_ROW_WSTEPS], g1[ASX_ROW_WSTEPS];
             static_for<0, ASX_ROW_WSTEPS>([&](auto I) __attribute__((always_inline)) {
@@ -677,7 +688,11 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_inv_cols(const AsxDe
     if constexpr (STATIC) { T = TC; logT = asx_ilog2(TC); M1 = S1::n; nthreads = NT; }
     const int logH = logT - 1, H = T >> 1, M2 = P.M2;
     const int c0 = tile * T;
+#ifdef ASX_EXP_PAIR0
+    const float2 *in = ga;
+#else
     const float2 *in = ga + pair * (size_t)P.M;
+#endif
     const bool even = (M2 & 1) == 0;
     float4 *lds4 = reinterpret_cast<float4 *>(asx_lds);
 
