@@ -421,7 +421,9 @@ __device__ __forceinline__ void lds_stage(float4 *lds, const StageK K, const Lds
     const int ns = K.ns, q = K.q, nbf = K.nbf, twmul = K.twmul;
     const float inv_q = K.inv_q, inv_nbf = K.inv_nbf;
     const int total = L.ngroups * nbf;
+#ifndef ASX_EXP_NOCONF
     const int step = q * L.elem_stride;
+#endif
     for (int w = threadIdx.x; w < total; w += L.nthreads) {
         int g, bf;
         if (GFAST) {
@@ -434,7 +436,12 @@ __device__ __forceinline__ void lds_stage(float4 *lds, const StageK K, const Lds
         if (UNIT_TW) { b = bf; j = 0; }                 // q == 1
         else if (nbf == q) { b = 0; j = bf; }           // first stage: one sub-block (wave-uniform test)
         else b = div_exact(bf, q, inv_q, j);
+#ifdef ASX_EXP_NOCONF /* experiment (wrong results): every stage addresses LDS like the first one, lanes on consecutive slots */
+        float4 *p = lds + g * L.group_stride + bf * L.elem_stride;
+        const int step = nbf * L.elem_stride;
+#else
         float4 *p = lds + g * L.group_stride + (b * ns + j) * L.elem_stride;
+#endif
         Cx2 v[R];
         static_for<0, R>([&](auto T) __attribute__((always_inline)) { v[T] = lds_get(p + T * step); });
         if constexpr (UNIT_TW) {

@@ -23,6 +23,17 @@
 #include <type_traits>
 #include <stdlib.h>
 
+// The file is compiled in parts so that a build uses all the cores (Makefile: one object per part):
+//   -DASX_PART=<bit mask>; no ASX_PART = everything in one translation unit.
+//   1 k_fwd_cols, compile-time schedules    2 k_fwd_cols, run-time schedules
+//   4 k_rows, compile-time schedules        8 k_rows, run-time schedules
+//   16 k_inv_cols, compile-time schedules   32 k_inv_cols, run-time schedules
+//   64 everything else (peak finalisation, refinement, Pearson, helpers, the launch dispatchers)
+#ifndef ASX_PART
+#define ASX_PART 127
+#endif
+#define ASX_HAS_PART(bit) ((ASX_PART & (bit)) != 0)
+
 // Diagnostic phase clocks (never in a shipped build; -DASX_STAMPS): lane 0 of every k_rows block
 // records s_memtime at phase boundaries into a buffer nothing else reads.
 #ifdef ASX_STAMPS
@@ -36,6 +47,11 @@
 #endif
 #define ASX_STAMP(slot) ASX_STAMP_AT(0, task, slot)
 
+// Diagnostic ablations of k_rows (-DASX_ABL=<mask>, wrong results, timing only): 1 no forward transforms,
+// 2 no spectral combine, 4 no inverse transforms, 8 every block reads and writes the rows of task 0 (cache hits).
+#ifndef ASX_ABL
+#define ASX_ABL 0
+#endif
 #ifndef ASX_ROWS_MIN_WAVES
 #define ASX_ROWS_MIN_WAVES 4   // k_rows fits 128 VGPRs (92-119 by variant): four blocks per CU, which is also what its LDS allows
 #endif
@@ -86,15 +102,23 @@ __device__ __forceinline__ float wave_sum_f32(float v)
 // {re0, im0, re1, im1} (lds_fft.h), so one thread transforms two columns with shared
 // twiddles and b128 LDS accesses, and tiles move in and out without a shuffle.
 // ---------------------------------------------------------------------------
-// Tile <-> block mapping of the column kernels.  With T = 8 a tile row is a 64-byte segment,
-// half of a 128-byte L2 line; the neighbouring tile owns the other half.  Blocks are dealt
-// round-robin over the 8 XCDs (each with a private L2), so with the identity mapping the two
-// halves are fetched by two different L2s: the PMC read counters showed exactly 2x the needed
-// bytes.  This mapping puts tiles 2i and 2i+1 on blocks b and b+8 (same XCD, dispatched
-// together), so the second half hits in L2.  Speed only; any placement is correct.
-__device__ __forceinline__ int col_tile_of_block(int b)
+// Tile <-> block mapping of the column kernels.  A tile row is T complex values = 8T bytes; L = 16/T tiles
+// share a 128-byte L2 line (T = 8: two tiles, 64 bytes each).  Blocks are dealt round-robin over the 8
+// XCDs (each with a private L2), so with the identity mapping the pieces of a line are fetched by different
+// L2s: the PMC read counters showed exactly 2x the needed bytes at T = 8.  This mapping puts the L tiles of
+// a line on blocks b, b + 8, ..., b + 8(L-1) (same XCD, dispatched together), so all but the first hit in
+// L2.  Speed only; any placement is correct.  Grids are rounded up to a multiple of 8L blocks.
+__device__ __host__ __forceinline__ int col_tiles_per_line_log(int logT) { return logT >= 4 ? 0 : 4 - logT; }
+__device__ __forceinline__ int col_tile_of_block(int b, int logT)
 {
-    return (b & ~15) + 2 * (b & 7) + ((b >> 3) & 1);
+    const int ll = col_tiles_per_line_log(logT);       // log2 L
+    const int grp = 8 << ll;                           // blocks that cover 8 lines
+    return (b & ~(grp - 1)) + ((b & 7) << ll) + ((b >> 3) & ((1 << ll) - 1));
+}
+static inline unsigned col_grid_x(int ntiles, int logT)
+{
+    const unsigned grp = 8u << col_tiles_per_line_log(logT);
+    return ((unsigned)ntiles + grp - 1) / grp * grp;
 }
 
 __device__ __forceinline__ LdsLayout col_layout(int T, int logT, int nthreads)
@@ -126,21 +150,25 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_fwd_cols(const AsxDe
     const AsxDev &PD = *Pp; // the plan lives in device memory: uniform scalar loads, taken once
     const AsxKP P = asx_kp(PD);
     __shared__ float nrm_red[ASX_FFT_THREADS_MAX / 64];
-    const int tile = col_tile_of_block(blockIdx.x);
-    if (tile >= P.ntiles) return; // grid.x is rounded up to a multiple of 16
     const bool is_smp = blockIdx.y != 0;
     const size_t pair = blockIdx.z;
     constexpr bool STATIC = !std::is_void<S1>::value;
     int T = P.T, logT = P.logT, M1 = P.M1;
     int nthreads = blockDim.x;
     if constexpr (STATIC) { T = TC; logT = asx_ilog2(TC); M1 = S1::n; nthreads = NT; }
+    const int tile = col_tile_of_block(blockIdx.x, logT);
+    if (tile >= P.ntiles) return; // grid.x is rounded up (col_grid_x)
     const int logH = logT - 1, H = T >> 1, M2 = P.M2;
     const int c0 = tile * T;
 
     const float *in = is_smp ? smp + pair * (size_t)P.N : src + pair * (size_t)P.src_period;
     const uint32_t valid = is_smp ? P.N : P.src_valid;      // real samples that are not zero padding
     const uint32_t period = is_smp ? P.N : P.src_period;    // source may be periodically extended
+#ifdef ASX_EXP_PAIRMOD
+    float2 *out = (is_smp ? zya : zxa) + (pair % ASX_EXP_PAIRMOD) * (size_t)P.M;
+#else
     float2 *out = (is_smp ? zya : zxa) + pair * (size_t)P.M;
+#endif
     const bool even = (M2 & 1) == 0;
     const bool vec_in = even && ((reinterpret_cast<uintptr_t>(in) & 15u) == 0);
     float4 *lds4 = reinterpret_cast<float4 *>(asx_lds);
@@ -306,8 +334,10 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, ASX_ROWS_MIN_WAVES) void k_row
     {
         const int pair = task / nrows;
         const int4 rt = row_tasks[task - pair * nrows];
-        const int pa = rt.x, pb = rt.y, k1 = rt.z, m1 = rt.w;
+        int pa = rt.x, pb = rt.y;
+        const int k1 = rt.z, m1 = rt.w;
         const bool self = (k1 == m1);
+        if (ASX_ABL & 8) { pa = 1; pb = 2; }
         ASX_STAMP(0);
         if (k1 == 0 && threadIdx.x < 64) {
             // Row 0 of a pair also prepares the pair's peak search (k_inv_cols runs after this kernel):
@@ -338,8 +368,8 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, ASX_ROWS_MIN_WAVES) void k_row
         RowRegs L;
         RowRegsWide LW;
         {
-#ifdef ASX_EXP_PAIR0 /* experiment: all traffic of the kernel falls on pair 0's rows (Infinity-Cache resident) */
-            const float2 *gx = zxa, *gy = zya;
+#ifdef ASX_EXP_PAIRMOD /* experiment (wrong results): the intermediates of all pairs fall on those of the first ASX_EXP_PAIRMOD pairs (Infinity-Cache resident) */
+            const float2 *gx = zxa + (size_t)(pair % ASX_EXP_PAIRMOD) * M, *gy = zya + (size_t)(pair % ASX_EXP_PAIRMOD) * M;
 #else
             const float2 *gx = zxa + (size_t)pair * M, *gy = zya + (size_t)pair * M;
 #endif
@@ -423,8 +453,10 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, ASX_ROWS_MIN_WAVES) void k_row
         }
         __syncthreads();
         ASX_STAMP(1);
+        if (!(ASX_ABL & 1)) {
         if constexpr (STATIC) lds_fft_static<S2, false, false>(A4, Lf, P.tw2, pre_f);
         else lds_fft<MAXR, false, false>(A4, PD.st2, Lf, P.tw2, pre_f);
+        }
         ASX_STAMP(2);
 
         // ---- spectral combine.  Every thread first computes its G values into registers (it
@@ -433,7 +465,9 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, ASX_ROWS_MIN_WAVES) void k_row
         const float2 wA = wk1; // w_M^k1, block-uniform; w_M^(k1 + M1*k2) = wA * w_M2^k2
         float2 gk[ASX_ROW_STEPS], gm[ASX_ROW_STEPS];
         int sa[ASX_ROW_STEPS], sb[ASX_ROW_STEPS]; // -1: nothing to write
-        if (!self) {
+        if (ASX_ABL & 2) {
+            static_for<0, ASX_ROW_STEPS>([&](auto I) __attribute__((always_inline)) { sa[I] = -1; sb[I] = -1; });
+        } else if (!self) {
             // The common case.  A thread walks SLOTS s = t + i*nthreads, not bins: consecutive lanes read
             // consecutive slots of A and (digit reversal complements every digit: the partner bin
             // M2-1-k2 sits at slot M2-1-s) consecutive slots of B, backwards -- no bank conflicts, no
@@ -513,16 +547,18 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, ASX_ROWS_MIN_WAVES) void k_row
 
         ASX_STAMP(3);
         // inverse row transforms of the G pair, digit-reversed in -> natural j2 out
+        if (!(ASX_ABL & 4)) {
         if constexpr (STATIC) lds_fft_static<S2, true, false>(A4, Li, P.tw2, pre_i);
         else lds_fft<MAXR, true, false>(A4, PD.st2, Li, P.tw2, pre_i);
+        }
         ASX_STAMP(4);
 
         // inverse four-step twiddle conj(w_M^(k1*j2)) / conj(w_M^(m1*j2)), one per member; unrolled so
         // that the LDS reads of all steps are in flight together (a rolled loop pays the LDS latency
         // once per step).  twa / twb ride in registers from the load phase.  Even rows leave as 16
         // bytes per lane, like they came.
-#ifdef ASX_EXP_PAIR0
-        float2 *go = ga;
+#ifdef ASX_EXP_PAIRMOD
+        float2 *go = ga + (size_t)(pair % ASX_EXP_PAIRMOD) * M;
 #else
         float2 *go = ga + (size_t)pair * M;
 #endif
@@ -679,17 +715,17 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_inv_cols(const AsxDe
     const AsxDev &PD = *Pp; // the plan lives in device memory: uniform scalar loads, taken once
     const AsxKP P = asx_kp(PD);
     __shared__ asx_peak_t red[ASX_FFT_THREADS_MAX / 64];
-    const int tile = col_tile_of_block(blockIdx.x);
-    if (tile >= P.ntiles) return; // grid.x is rounded up to a multiple of 16
     const size_t pair = blockIdx.y;
     constexpr bool STATIC = !std::is_void<S1>::value;
     int T = P.T, logT = P.logT, M1 = P.M1;
     int nthreads = blockDim.x;
     if constexpr (STATIC) { T = TC; logT = asx_ilog2(TC); M1 = S1::n; nthreads = NT; }
+    const int tile = col_tile_of_block(blockIdx.x, logT);
+    if (tile >= P.ntiles) return; // grid.x is rounded up (col_grid_x)
     const int logH = logT - 1, H = T >> 1, M2 = P.M2;
     const int c0 = tile * T;
-#ifdef ASX_EXP_PAIR0
-    const float2 *in = ga;
+#ifdef ASX_EXP_PAIRMOD
+    const float2 *in = ga + (pair % ASX_EXP_PAIRMOD) * (size_t)P.M;
 #else
     const float2 *in = ga + pair * (size_t)P.M;
 #endif
@@ -860,6 +896,7 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_inv_cols(const AsxDe
     ASX_STAMP_AT(2, stamp_block, 3);
 }
 
+#if ASX_HAS_PART(64)
 // ---------------------------------------------------------------------------
 // k_finalize: grid (npairs).  Reduce tile partials, wrap the lag, pick segments.
 // ---------------------------------------------------------------------------
@@ -1242,11 +1279,144 @@ __global__ __launch_bounds__(ASX_THREADS) void k_synth(uint64_t seed, uint64_t f
     if (true_lag && blockIdx.x == 0 && threadIdx.x == 0) true_lag[blockIdx.y] = lag;
 }
 
+#endif // ASX_HAS_PART(64)
+
 // ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
-size_t asx_lds_bytes_cols(const AsxDev &P) { return (size_t)P.M1 * P.T * sizeof(float2); }
-size_t asx_lds_bytes_rows(const AsxDev &P) { return (size_t)4 * P.M2 * sizeof(float2); }
+static size_t lds_bytes_cols(const AsxDev &P) { return (size_t)P.M1 * P.T * sizeof(float2); }
+static size_t lds_bytes_rows(const AsxDev &P) { return (size_t)4 * P.M2 * sizeof(float2); }
+
+static int max_radix(const AsxStages &st)
+{
+    int m = 2;
+    for (int i = 0; i < st.nstages; i++) m = st.radix[i] > m ? st.radix[i] : m;
+    return m;
+}
+
+static void allow_big_lds(const void *fn, size_t bytes)
+{
+    if (bytes > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+static bool schedule_is(const AsxStages &st, int n, std::initializer_list<int> radices)
+{
+    if (st.n != n || st.nstages != (int)radices.size()) return false;
+    int i = 0;
+    for (int r : radices)
+        if (st.radix[i++] != r) return false;
+    return true;
+}
+// Column schedules of the production sample lengths (plan_math.cpp's tuned table), compiled in:
+//   X(M1, tile width, block size, MAXR for the launch bounds, radices...)
+#define ASX_STATIC_COLS(X) \
+    X(1200, 8, 512, 12, 12, 10, 10) X(800, 8, 320, 10, 10, 10, 8) X(600, 16, 512, 10, 10, 10, 6) \
+    X(400, 16, 320, 10, 10, 8, 5) X(300, 16, 256, 10, 10, 6, 5)
+
+// Every transform kernel has two launchers, each in its own part of the build: *_static returns false
+// when no compiled-in schedule matches the plan, *_generic takes any plan.
+bool asx_launch_fwd_cols_static(const AsxDev &P, const float *src, const float *smp, float2 *zxa, float2 *zya,
+                                const AsxPeakWs &W, int npairs, hipStream_t s);
+void asx_launch_fwd_cols_generic(const AsxDev &P, const float *src, const float *smp, float2 *zxa, float2 *zya,
+                                 const AsxPeakWs &W, int npairs, hipStream_t s);
+bool asx_launch_rows_static(const AsxDev &P, const float2 *zxa, const float2 *zya, float2 *ga, const AsxPeakWs &W,
+                            int npairs, hipStream_t s);
+void asx_launch_rows_generic(const AsxDev &P, const float2 *zxa, const float2 *zya, float2 *ga, const AsxPeakWs &W,
+                             int npairs, hipStream_t s);
+bool asx_launch_inv_cols_static(const AsxDev &P, const float2 *ga, const AsxPeakWs &W, float *r_out, int npairs,
+                                hipStream_t s);
+void asx_launch_inv_cols_generic(const AsxDev &P, const float2 *ga, const AsxPeakWs &W, float *r_out, int npairs,
+                                 hipStream_t s);
+
+#define ASX_FWD_LAUNCH(...) \
+    do { allow_big_lds((const void *)k_fwd_cols<__VA_ARGS__>, lds_bytes_cols(P)); \
+         hipLaunchKernelGGL((k_fwd_cols<__VA_ARGS__>), grid, dim3(P.threads_cols), lds_bytes_cols(P), s, P.self_dev, src, smp, zxa, zya, W.nrm_part); } while (0)
+#if ASX_HAS_PART(1)
+bool asx_launch_fwd_cols_static(const AsxDev &P, const float *src, const float *smp, float2 *zxa, float2 *zya,
+                                const AsxPeakWs &W, int npairs, hipStream_t s)
+{
+    dim3 grid(col_grid_x(P.ntiles, P.logT), 2, npairs);
+#define ASX_TRY_STATIC(m1, t, nt, maxr, ...) \
+    if (P.T == (t) && P.threads_cols == (nt) && schedule_is(P.st1, m1, { __VA_ARGS__ })) { ASX_FWD_LAUNCH(maxr, Sched<m1, __VA_ARGS__>, t, nt); return true; }
+    ASX_STATIC_COLS(ASX_TRY_STATIC)
+#undef ASX_TRY_STATIC
+    return false;
+}
+#endif
+#if ASX_HAS_PART(2)
+void asx_launch_fwd_cols_generic(const AsxDev &P, const float *src, const float *smp, float2 *zxa, float2 *zya,
+                                 const AsxPeakWs &W, int npairs, hipStream_t s)
+{
+    dim3 grid(col_grid_x(P.ntiles, P.logT), 2, npairs);
+    const int mr = max_radix(P.st1);
+    if (mr <= 10) ASX_FWD_LAUNCH(10); else if (mr <= 12) ASX_FWD_LAUNCH(12); else ASX_FWD_LAUNCH(16);
+}
+#endif
+#undef ASX_FWD_LAUNCH
+
+#define ASX_ROWS_LAUNCH(...) \
+    do { allow_big_lds((const void *)k_rows<__VA_ARGS__>, lds); \
+         hipLaunchKernelGGL((k_rows<__VA_ARGS__>), dim3(ntasks), dim3(P.threads_rows), lds, s, P.self_dev, zxa, zya, ga, P.row_tasks, P.M1, P.M2, P.M, W); } while (0)
+static size_t rows_lds_request(const AsxDev &P)
+{
+    size_t lds = lds_bytes_rows(P);
+    // diagnostic: a larger request caps the blocks per CU (occupancy sweep, tools/README.md)
+    if (const char *e = getenv("ASX_DBG_ROWS_LDS")) lds = std::max(lds, (size_t)atol(e));
+    return lds;
+}
+#if ASX_HAS_PART(4)
+// row lengths of the production sample lengths (plan_math.cpp's tuned table): schedule compiled in
+bool asx_launch_rows_static(const AsxDev &P, const float2 *zxa, const float2 *zya, float2 *ga, const AsxPeakWs &W,
+                            int npairs, hipStream_t s)
+{
+    const int ntasks = (P.M1 / 2 + 1) * npairs; // one task (pair, k1) per block
+    const size_t lds = rows_lds_request(P);
+    if (P.threads_rows == 256 && schedule_is(P.st2, 1200, { 12, 10, 10 })) { ASX_ROWS_LAUNCH(12, Sched<1200, 12, 10, 10>, 256); return true; }
+    if (P.threads_rows == 128 && schedule_is(P.st2, 480, { 10, 8, 6 })) { ASX_ROWS_LAUNCH(10, Sched<480, 10, 8, 6>, 128); return true; }
+    return false;
+}
+#endif
+#if ASX_HAS_PART(8)
+void asx_launch_rows_generic(const AsxDev &P, const float2 *zxa, const float2 *zya, float2 *ga, const AsxPeakWs &W,
+                             int npairs, hipStream_t s)
+{
+    const int ntasks = (P.M1 / 2 + 1) * npairs;
+    const size_t lds = rows_lds_request(P);
+    const int mr = max_radix(P.st2);
+    if (mr <= 10) ASX_ROWS_LAUNCH(10); else if (mr <= 12) ASX_ROWS_LAUNCH(12); else ASX_ROWS_LAUNCH(16);
+}
+#endif
+#undef ASX_ROWS_LAUNCH
+
+#define ASX_INV_LAUNCH(...) \
+    do { allow_big_lds((const void *)k_inv_cols<__VA_ARGS__>, lds_bytes_cols(P)); \
+         hipLaunchKernelGGL((k_inv_cols<__VA_ARGS__>), grid, dim3(P.threads_cols), lds_bytes_cols(P), s, P.self_dev, ga, W, r_out); } while (0)
+#if ASX_HAS_PART(16)
+bool asx_launch_inv_cols_static(const AsxDev &P, const float2 *ga, const AsxPeakWs &W, float *r_out, int npairs,
+                                hipStream_t s)
+{
+    dim3 grid(col_grid_x(P.ntiles, P.logT), npairs);
+#define ASX_TRY_STATIC(m1, t, nt, maxr, ...) \
+    if (P.T == (t) && P.threads_cols == (nt) && schedule_is(P.st1, m1, { __VA_ARGS__ })) { ASX_INV_LAUNCH(maxr, Sched<m1, __VA_ARGS__>, t, nt); return true; }
+    ASX_STATIC_COLS(ASX_TRY_STATIC)
+#undef ASX_TRY_STATIC
+    return false;
+}
+#endif
+#if ASX_HAS_PART(32)
+void asx_launch_inv_cols_generic(const AsxDev &P, const float2 *ga, const AsxPeakWs &W, float *r_out, int npairs,
+                                 hipStream_t s)
+{
+    dim3 grid(col_grid_x(P.ntiles, P.logT), npairs);
+    const int mr = max_radix(P.st1);
+    if (mr <= 10) ASX_INV_LAUNCH(10); else if (mr <= 12) ASX_INV_LAUNCH(12); else ASX_INV_LAUNCH(16);
+}
+#endif
+#undef ASX_INV_LAUNCH
+
+#if ASX_HAS_PART(64)
+size_t asx_lds_bytes_cols(const AsxDev &P) { return lds_bytes_cols(P); }
+size_t asx_lds_bytes_rows(const AsxDev &P) { return lds_bytes_rows(P); }
 
 // Block size: a multiple of 64 (<= ASX_FFT_THREADS_MAX).  First enough waves per CU to hide
 // LDS/HBM latency given how many blocks the LDS footprint admits (target >= 12 waves per CU),
@@ -1275,94 +1445,31 @@ int asx_pick_threads(const AsxStages &st, int groups, int min_threads, size_t ld
     return best;
 }
 
-static int asx_cu_count()
-{
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return 256;
-    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) return 256;
-    return n;
-}
-
-static int max_radix(const AsxStages &st)
-{
-    int m = 2;
-    for (int i = 0; i < st.nstages; i++) m = st.radix[i] > m ? st.radix[i] : m;
-    return m;
-}
-
-static void allow_big_lds(const void *fn, size_t bytes)
-{
-    if (bytes > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-}
-
-static bool schedule_is(const AsxStages &st, int n, std::initializer_list<int> radices)
-{
-    if (st.n != n || st.nstages != (int)radices.size()) return false;
-    int i = 0;
-    for (int r : radices)
-        if (st.radix[i++] != r) return false;
-    return true;
-}
 static bool generic_only()
 {
     static const bool g = getenv("ASX_GENERIC") != nullptr; // diagnostic: never use the compiled-in schedules
     return g;
 }
-// Column schedules of the production sample lengths (plan_math.cpp's tuned table), compiled in:
-//   X(M1, tile width, block size, MAXR for the launch bounds, radices...)
-#define ASX_STATIC_COLS(X) \
-    X(1200, 8, 512, 12, 12, 10, 10) X(800, 8, 320, 10, 10, 10, 8) X(600, 16, 512, 10, 10, 10, 6) \
-    X(400, 16, 320, 10, 10, 8, 5) X(300, 16, 256, 10, 10, 6, 5)
 
 void asx_launch_fwd_cols(const AsxDev &P, const float *src, const float *smp, float2 *zxa,
                          float2 *zya, const AsxPeakWs &W, int npairs, hipStream_t s)
 {
-    dim3 grid((P.ntiles + 15) / 16 * 16, 2, npairs);
-#define ASX_LAUNCH(...) \
-    do { allow_big_lds((const void *)k_fwd_cols<__VA_ARGS__>, asx_lds_bytes_cols(P)); \
-         hipLaunchKernelGGL((k_fwd_cols<__VA_ARGS__>), grid, dim3(P.threads_cols), asx_lds_bytes_cols(P), s, P.self_dev, src, smp, zxa, zya, W.nrm_part); } while (0)
-#define ASX_TRY_STATIC(m1, t, nt, maxr, ...) \
-    if (!generic_only() && P.T == (t) && P.threads_cols == (nt) && schedule_is(P.st1, m1, { __VA_ARGS__ })) { ASX_LAUNCH(maxr, Sched<m1, __VA_ARGS__>, t, nt); return; }
-    ASX_STATIC_COLS(ASX_TRY_STATIC)
-#undef ASX_TRY_STATIC
-    const int mr = max_radix(P.st1);
-    if (mr <= 10) ASX_LAUNCH(10); else if (mr <= 12) ASX_LAUNCH(12); else ASX_LAUNCH(16);
-#undef ASX_LAUNCH
+    if (generic_only() || !asx_launch_fwd_cols_static(P, src, smp, zxa, zya, W, npairs, s))
+        asx_launch_fwd_cols_generic(P, src, smp, zxa, zya, W, npairs, s);
 }
 
 void asx_launch_rows(const AsxDev &P, const float2 *zxa, const float2 *zya, float2 *ga,
                      const AsxPeakWs &W, int npairs, hipStream_t s)
 {
-    const int ntasks = (P.M1 / 2 + 1) * npairs;
-    size_t lds = asx_lds_bytes_rows(P);
-    // diagnostic: a larger request caps the blocks per CU (occupancy sweep, tools/README.md)
-    if (const char *e = getenv("ASX_DBG_ROWS_LDS")) lds = std::max(lds, (size_t)atol(e));
-#define ASX_LAUNCH(...) \
-    do { allow_big_lds((const void *)k_rows<__VA_ARGS__>, lds); \
-         int grid = ntasks; /* one task (pair, k1) per block */ \
-         hipLaunchKernelGGL((k_rows<__VA_ARGS__>), dim3(grid), dim3(P.threads_rows), lds, s, P.self_dev, zxa, zya, ga, P.row_tasks, P.M1, P.M2, P.M, W); } while (0)
-    const int mr = max_radix(P.st2);
-    // row lengths of the production sample lengths (plan_math.cpp's tuned table): schedule compiled in
-    if (!generic_only() && P.threads_rows == 256 && schedule_is(P.st2, 1200, { 12, 10, 10 })) ASX_LAUNCH(12, Sched<1200, 12, 10, 10>, 256);
-    else if (!generic_only() && P.threads_rows == 128 && schedule_is(P.st2, 480, { 10, 8, 6 })) ASX_LAUNCH(10, Sched<480, 10, 8, 6>, 128);
-    else if (mr <= 10) ASX_LAUNCH(10); else if (mr <= 12) ASX_LAUNCH(12); else ASX_LAUNCH(16);
-#undef ASX_LAUNCH
+    if (generic_only() || !asx_launch_rows_static(P, zxa, zya, ga, W, npairs, s))
+        asx_launch_rows_generic(P, zxa, zya, ga, W, npairs, s);
 }
 
 void asx_launch_inv_cols(const AsxDev &P, const float2 *ga, const AsxPeakWs &W, float *r_out, int npairs,
                          hipStream_t s)
 {
-    dim3 grid((P.ntiles + 15) / 16 * 16, npairs);
-#define ASX_LAUNCH(...) \
-    do { allow_big_lds((const void *)k_inv_cols<__VA_ARGS__>, asx_lds_bytes_cols(P)); \
-         hipLaunchKernelGGL((k_inv_cols<__VA_ARGS__>), grid, dim3(P.threads_cols), asx_lds_bytes_cols(P), s, P.self_dev, ga, W, r_out); } while (0)
-#define ASX_TRY_STATIC(m1, t, nt, maxr, ...) \
-    if (!generic_only() && P.T == (t) && P.threads_cols == (nt) && schedule_is(P.st1, m1, { __VA_ARGS__ })) { ASX_LAUNCH(maxr, Sched<m1, __VA_ARGS__>, t, nt); return; }
-    ASX_STATIC_COLS(ASX_TRY_STATIC)
-#undef ASX_TRY_STATIC
-    const int mr = max_radix(P.st1);
-    if (mr <= 10) ASX_LAUNCH(10); else if (mr <= 12) ASX_LAUNCH(12); else ASX_LAUNCH(16);
-#undef ASX_LAUNCH
+    if (generic_only() || !asx_launch_inv_cols_static(P, ga, W, r_out, npairs, s))
+        asx_launch_inv_cols_generic(P, ga, W, r_out, npairs, s);
 }
 
 void asx_launch_finalize(const AsxDev &P, const AsxPeakWs &W, AsxSeg *seg, int npairs, hipStream_t s)
@@ -1429,3 +1536,4 @@ void asx_launch_synth(uint64_t seed, uint64_t first_pair, size_t count, uint32_t
     hipLaunchKernelGGL(k_synth, dim3(bx, (unsigned)count), dim3(ASX_THREADS), 0, s, seed, first_pair, N,
                        amp, src, smp, true_lag);
 }
+#endif // ASX_HAS_PART(64)
