@@ -382,12 +382,6 @@ __device__ __forceinline__ TwPre tw_prefetch(const AsxStages &st, int i, const L
     if (i < 0 || i >= st.nstages) return TwPre{ make_float2(1.f, 0.f), make_float2(1.f, 0.f) };
     return tw_prefetch_k<GFAST>(stage_k(st, i), L, tw);
 }
-// first stage to run of a compile-time schedule
-template <class S, bool INV, bool GFAST>
-__device__ __forceinline__ TwPre tw_prefetch_first(const LdsLayout &L, const float2 *__restrict__ tw)
-{
-    return tw_prefetch_k<GFAST>(S::stage(INV ? S::nstages - 1 : 0), L, tw);
-}
 
 // Stage twiddles from (W^1, W^4): products of depth <= 3
 template <int R> __device__ __forceinline__ void stage_twiddles_from(float2 w1, float2 w4, float2 (&w)[R])
@@ -529,21 +523,173 @@ __device__ __forceinline__ void lds_fft(float4 *lds, const AsxStages &st, const 
     }
 }
 
+// ---- two consecutive stages without a block barrier between them ---------------------------------
+// DIF stages I and I+1 of a schedule both stay inside the sub-blocks of length ns_I ("units").  When
+// their radices are equal, a unit has the same number Q = ns_I / R of butterflies in both stages, so a
+// WAVE that owns whole units (64 / Q of them, Q lanes each) can run both stages on them back to back:
+// LDS operations of one wave execute in order, nothing another wave touches is involved, and the
+// s_barrier between the two stages (with the wait for the slowest of the block's waves) disappears.
+// Forward runs stage I then I+1, inverse I+1 then I.  Units are numbered over (pair, sub-block);
+// GFAST walks the pair index first, like lds_stage.
+template <class S, int I> struct WavePair {
+    static constexpr StageK K0 = S::stage(I), K1 = S::stage(I + 1);
+    static constexpr int R = K0.R, Q = K0.q, UPW = Q <= 64 ? 64 / Q : 0, NSUB = S::n / K0.ns;
+    static constexpr bool ok = (I + 1 < S::nstages) && K0.R == K1.R && Q >= 1 && Q <= 64;
+};
+template <class S, int I> constexpr bool wave_pair_ok()
+{
+    if constexpr (I + 1 < S::nstages) return WavePair<S, I>::ok;
+    else return false;
+}
+
+template <class S, int I, bool GFAST>
+__device__ __forceinline__ TwPre tw_prefetch_wavepair(const LdsLayout &L, const float2 *__restrict__ tw)
+{
+    using WP = WavePair<S, I>;
+    TwPre pre{ make_float2(1.f, 0.f), make_float2(1.f, 0.f) };
+    const int lane = threadIdx.x & 63;
+    if (WP::K0.q == 1 || lane >= WP::UPW * WP::Q) return pre;
+    const int j = lane % WP::Q;
+    const int tj = j * WP::K0.twmul;
+    pre.w1 = tw[tj];
+    if (WP::R > 4) pre.w4 = tw[4 * tj];
+    return pre;
+}
+
+template <class S, int I, bool INV, bool GFAST>
+__device__ __forceinline__ void lds_stage_wavepair(float4 *lds, const LdsLayout &L, const float2 *__restrict__ tw, TwPre pre)
+{
+    using WP = WavePair<S, I>;
+    constexpr int R = WP::R, Q = WP::Q, UPW = WP::UPW;
+    constexpr StageK K0 = WP::K0, K1 = WP::K1;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = L.nthreads >> 6;
+    const int nunits = L.ngroups * WP::NSUB;
+    const int ul = lane / Q, j = lane - ul * Q;   // unit within the wave, butterfly within the unit
+    for (int u0 = wave * UPW; u0 < nunits; u0 += nwaves * UPW) { // wave-uniform trip count
+        const int unit = u0 + ul;
+        const bool active = (ul < UPW) && (unit < nunits);
+        int g, b;
+        if (GFAST) { g = unit & (L.ngroups - 1); b = unit >> L.log_ngroups; }
+        else { g = unit / WP::NSUB; b = unit - g * WP::NSUB; }
+        float4 *base = lds + g * L.group_stride + (b * K0.ns) * L.elem_stride;
+        // stage I: butterfly j of the unit, legs Q elements apart; stage I+1: butterfly j, sub-block j of the unit
+        float4 *p0 = base + j * L.elem_stride;
+        const int b1 = j / K1.q, j1 = j - b1 * K1.q; // stage I+1: sub-block b1 of the unit, position j1
+        float4 *p1 = base + (b1 * K1.ns + j1) * L.elem_stride;
+        const int step0 = K0.q * L.elem_stride, step1 = K1.q * L.elem_stride;
+        auto run = [&](auto WHICH) __attribute__((always_inline)) {
+            constexpr bool first = decltype(WHICH)::value == 0; // stage I (twiddled unless q == 1)
+            constexpr StageK K = first ? K0 : K1;
+            float4 *p = first ? p0 : p1;
+            const int step = first ? step0 : step1;
+            if (active) {
+                Cx2 v[R];
+                static_for<0, R>([&](auto T) __attribute__((always_inline)) { v[T] = lds_get(p + T * step); });
+                if constexpr (K.q == 1) {
+                    Bfly<R, INV>::run(v);
+                } else {
+                    float2 w1 = pre.w1, w4 = pre.w4;
+                    if (!first) { // stage I+1 with q > 1: its own twiddles (position inside its sub-block)
+                        w1 = tw[j1 * K.twmul];
+                        if constexpr (R > 4) w4 = tw[4 * j1 * K.twmul];
+                    }
+                    float2 tww[R];
+                    stage_twiddles_from<R>(w1, w4, tww);
+                    if constexpr (!INV) {
+                        Bfly<R, false>::run(v);
+                        static_for<1, R>([&](auto U) __attribute__((always_inline)) { v[U] = mulw(v[U], tww[U]); });
+                    } else {
+                        static_for<1, R>([&](auto U) __attribute__((always_inline)) { v[U] = mulwc(v[U], tww[U]); });
+                        Bfly<R, true>::run(v);
+                    }
+                }
+                static_for<0, R>([&](auto T) __attribute__((always_inline)) { lds_put(p + T * step, v[T]); });
+            }
+        };
+        if constexpr (!INV) run(std::integral_constant<int, 0>{}); else run(std::integral_constant<int, 1>{});
+        // same wave, in-order LDS: the second stage reads what the first wrote once the writes are issued
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if constexpr (!INV) run(std::integral_constant<int, 1>{}); else run(std::integral_constant<int, 0>{});
+    }
+}
+
+// The same with a compile-time schedule S = Sched<n, radices...>: the stage loop is unrolled and
+// every stage is instantiated for its own radix and geometry only.
+// Execution plan of a compile-time schedule: stage I and I+1 run as a wave pair (no barrier between
+// them) for the LAST such I (ASX_WAVEPAIR, default on); every other stage is an ordinary block-wide stage.
+#ifndef ASX_WAVEPAIR
+#define ASX_WAVEPAIR 1
+#endif
+// HEAD: the last stage to execute is left to lds_last_stage_static and must stay a block-wide stage.
+template <class S, bool INV = false, bool HEAD = false, bool GFAST = false> constexpr int wave_pair_index()
+{
+    int r = -1;
+    // Row kernels only.  In a column tile (GFAST) a wave that owns whole units has its lanes 40 slots apart
+    // in the innermost stage: 8-way bank conflicts, k_inv_cols 0.46 -> 0.69 ms [measured].
+    if (GFAST) return -1;
+#if ASX_WAVEPAIR
+    if constexpr (S::nstages >= 2) { if (wave_pair_ok<S, 0>()) r = 0; }
+    if constexpr (S::nstages >= 3) { if (wave_pair_ok<S, 1>()) r = 1; }
+    if constexpr (S::nstages >= 4) { if (wave_pair_ok<S, 2>()) r = 2; }
+#endif
+    constexpr int last = INV ? 0 : S::nstages - 1;
+    if (HEAD && r >= 0 && (last == r || last == r + 1)) r = -1;
+    return r;
+}
+// twiddle prefetch of stage i as it will be executed (wave-pair mapping or block mapping)
+template <class S, int i, bool GFAST, bool INV = false, bool HEAD = false>
+__device__ __forceinline__ TwPre tw_prefetch_exec(const LdsLayout &L, const float2 *__restrict__ tw)
+{
+    constexpr int WPI = wave_pair_index<S, INV, HEAD, GFAST>();
+    if constexpr (i < 0 || i >= S::nstages) return TwPre{ make_float2(1.f, 0.f), make_float2(1.f, 0.f) };
+    else if constexpr (WPI >= 0 && (i == WPI || i == WPI + 1)) return tw_prefetch_wavepair<S, WPI, GFAST>(L, tw);
+    else return tw_prefetch_k<GFAST>(S::stage(i), L, tw);
+}
+// first stage to run of a compile-time schedule
+template <class S, bool INV, bool GFAST, bool HEAD = false>
+__device__ __forceinline__ TwPre tw_prefetch_first(const LdsLayout &L, const float2 *__restrict__ tw)
+{
+    return tw_prefetch_exec<S, (INV ? S::nstages - 1 : 0), GFAST, INV, HEAD>(L, tw);
+}
+
+// Runs the stages [FIRST_STEP, FIRST_STEP + NSTEPS) of the execution order (forward: stage = step;
+// inverse: stage = nstages - 1 - step), each followed by a barrier; returns the prefetch of the next step.
+template <class S, bool INV, bool GFAST, int NSTEPS, bool HEAD = false>
+__device__ __forceinline__ TwPre lds_fft_static_steps(float4 *lds, const LdsLayout &L, const float2 *__restrict__ tw, TwPre pre)
+{
+    constexpr int WPI = wave_pair_index<S, INV, HEAD, GFAST>();
+    static_for<0, NSTEPS>([&](auto I) __attribute__((always_inline)) {
+        constexpr int i = INV ? S::nstages - 1 - decltype(I)::value : decltype(I)::value;
+        constexpr int inext = INV ? i - 1 : i + 1;
+        constexpr bool second_of_pair = WPI >= 0 && (INV ? i == WPI : i == WPI + 1);
+        constexpr bool first_of_pair = WPI >= 0 && (INV ? i == WPI + 1 : i == WPI);
+        if constexpr (second_of_pair) {
+            // already done together with its partner
+        } else if constexpr (first_of_pair) {
+            constexpr int iafter = INV ? WPI - 1 : WPI + 2;
+            const TwPre next = tw_prefetch_exec<S, iafter, GFAST, INV, HEAD>(L, tw);
+            lds_stage_wavepair<S, WPI, INV, GFAST>(lds, L, tw, pre);
+            pre = next;
+            __syncthreads();
+        } else {
+            constexpr StageK K = S::stage(i);
+            const TwPre next = tw_prefetch_exec<S, inext, GFAST, INV, HEAD>(L, tw);
+            lds_stage<K.R, INV, GFAST, K.q == 1>(lds, K, L, tw, pre);
+            pre = next;
+            __syncthreads();
+        }
+    });
+    return pre;
+}
+
 // The same with a compile-time schedule S = Sched<n, radices...>: the stage loop is unrolled and
 // every stage is instantiated for its own radix and geometry only.
 template <class S, bool INV, bool GFAST>
 __device__ __forceinline__ void lds_fft_static(float4 *lds, const LdsLayout &L, const float2 *__restrict__ tw, TwPre pre)
 {
-    static_for<0, S::nstages>([&](auto I) __attribute__((always_inline)) {
-        constexpr int i = INV ? S::nstages - 1 - decltype(I)::value : decltype(I)::value;
-        constexpr int inext = INV ? i - 1 : i + 1;
-        constexpr StageK K = S::stage(i);
-        TwPre next{ make_float2(1.f, 0.f), make_float2(1.f, 0.f) };
-        if constexpr (inext >= 0 && inext < S::nstages) next = tw_prefetch_k<GFAST>(S::stage(inext), L, tw);
-        lds_stage<K.R, INV, GFAST, K.q == 1>(lds, K, L, tw, pre);
-        pre = next;
-        __syncthreads();
-    });
+    (void)lds_fft_static_steps<S, INV, GFAST, S::nstages>(lds, L, tw, pre);
 }
 
 // ---- transforms whose LAST stage is consumed from registers (Sink) -------------------------------
@@ -592,16 +738,8 @@ __device__ __forceinline__ void lds_last_stage(float4 *lds, const AsxStages &st,
 template <class S, bool INV, bool GFAST>
 __device__ __forceinline__ TwPre lds_fft_static_head(float4 *lds, const LdsLayout &L, const float2 *__restrict__ tw, TwPre pre)
 {
-    static_for<0, S::nstages - 1>([&](auto I) __attribute__((always_inline)) {
-        constexpr int i = INV ? S::nstages - 1 - decltype(I)::value : decltype(I)::value;
-        constexpr int inext = INV ? i - 1 : i + 1;
-        constexpr StageK K = S::stage(i);
-        const TwPre next = tw_prefetch_k<GFAST>(S::stage(inext), L, tw);
-        lds_stage<K.R, INV, GFAST, K.q == 1>(lds, K, L, tw, pre);
-        pre = next;
-        __syncthreads();
-    });
-    return pre;
+    // HEAD: the stage left for lds_last_stage_static is never half of a wave pair (wave_pair_index)
+    return lds_fft_static_steps<S, INV, GFAST, S::nstages - 1, true>(lds, L, tw, pre);
 }
 template <class S, bool INV, bool GFAST, class Sink>
 __device__ __forceinline__ void lds_last_stage_static(float4 *lds, const LdsLayout &L, const float2 *__restrict__ tw, TwPre pre,

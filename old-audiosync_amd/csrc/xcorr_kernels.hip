@@ -326,7 +326,6 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, ASX_ROWS_MIN_WAVES) void k_row
     const AsxKP P = asx_kp(PD);
     const int nrows = M1 / 2 + 1;
     float4 *A4 = reinterpret_cast<float4 *>(asx_lds), *B4 = A4 + M2;
-    float2 *C2 = asx_lds; // the same storage seen as complex values: slot e = C2[2e] (member 0), C2[2e+1]
     __shared__ float2 tw_step[2][ASX_ROW_STEPS];
 
     // one task per block (grid = ntasks)
@@ -459,49 +458,70 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, ASX_ROWS_MIN_WAVES) void k_row
         }
         ASX_STAMP(2);
 
-        // ---- spectral combine.  Every thread first computes its G values into registers (it
-        // reads slots other threads will overwrite), then, after a barrier, scatters them:
-        // G[k] -> C[sa] member 0, G[M-k] -> C[sb] member 1 (member 0 for self-paired rows).
+        // ---- spectral combine: the same storage then holds C[e] = {Ga[e], Gb[e]}, the two rows of G.
         const float2 wA = wk1; // w_M^k1, block-uniform; w_M^(k1 + M1*k2) = wA * w_M2^k2
-        float2 gk[ASX_ROW_STEPS], gm[ASX_ROW_STEPS];
-        int sa[ASX_ROW_STEPS], sb[ASX_ROW_STEPS]; // -1: nothing to write
-        if (ASX_ABL & 2) {
-            static_for<0, ASX_ROW_STEPS>([&](auto I) __attribute__((always_inline)) { sa[I] = -1; sb[I] = -1; });
+        TwPre pre_i;
+        if ((ASX_ABL & 2) && !self) {
+            if constexpr (STATIC) pre_i = tw_prefetch_first<S2, true, false>(Li, P.tw2);
+            else pre_i = tw_prefetch<false>(PD.st2, PD.st2.nstages - 1, Li, P.tw2);
         } else if (!self) {
-            // The common case.  A thread walks SLOTS s = t + i*nthreads, not bins: consecutive lanes read
-            // consecutive slots of A and (digit reversal complements every digit: the partner bin
-            // M2-1-k2 sits at slot M2-1-s) consecutive slots of B, backwards -- no bank conflicts, no
-            // index table; the twiddle table is kept in slot order for this.  Three sweeps so that the
-            // table reads of all of a thread's slots are in flight together, then the LDS reads, then the
-            // arithmetic (slot by slot, each would wait for its own table read and its own LDS read).
-            float2 w2[ASX_ROW_STEPS];
-            static_for<0, ASX_ROW_STEPS>([&](auto I) __attribute__((always_inline)) {
+            // The common case.  A thread walks SLOT PAIRS (s, s' = M2-1-s), s = t + i*nthreads < M2/2, not bins:
+            // digit reversal complements every digit, so the partner bin M2-1-k2 of the bin at slot s sits at
+            // slot s'.  Bin(s) of row k1 pairs with bin(s') of row m1 and bin(s') of row k1 with bin(s) of row
+            // m1: the thread reads A[s], B[s'], A[s'], B[s] and writes C[s] = {G_k1[s], G_m1[s]} and C[s'] --
+            // nobody else touches these four slots, so there is NO barrier between the reads and the writes,
+            // the writes are whole 16-byte slots, consecutive lanes walk consecutive slots (forwards in s,
+            // backwards in s'): no bank conflicts, no index table (the twiddle table is kept in slot order).
+            // Sweeps: table reads of all steps in flight, then the LDS reads, then the arithmetic.
+            const int npairs2 = (M2 + 1) >> 1;
+            float2 w2a[ASX_ROW_WSTEPS], w2b[ASX_ROW_WSTEPS];
+            int sl[ASX_ROW_WSTEPS];
+            static_for<0, ASX_ROW_WSTEPS>([&](auto I) __attribute__((always_inline)) {
                 constexpr int i = decltype(I)::value;
-                const int s = threadIdx.x + i * nthreads;
-                const int sc = s < M2 ? s : 0; // clamped: the loads are unconditional
-                sa[i] = sc;
-                sb[i] = M2 - 1 - sc;
-                w2[i] = P.tw2s[sc];
+                const int sx = threadIdx.x + i * nthreads;
+                sl[i] = sx < npairs2 ? sx : 0; // clamped: the loads are unconditional
+                w2a[i] = P.tw2s[sl[i]];
+                w2b[i] = P.tw2s[M2 - 1 - sl[i]];
             });
-            Cx2 za[ASX_ROW_STEPS], zb[ASX_ROW_STEPS];
-            static_for<0, ASX_ROW_STEPS>([&](auto I) __attribute__((always_inline)) {
+            if constexpr (STATIC) pre_i = tw_prefetch_first<S2, true, false>(Li, P.tw2);
+            else pre_i = tw_prefetch<false>(PD.st2, PD.st2.nstages - 1, Li, P.tw2);
+            Cx2 za[ASX_ROW_WSTEPS], zb[ASX_ROW_WSTEPS], zc[ASX_ROW_WSTEPS], zd[ASX_ROW_WSTEPS];
+            static_for<0, ASX_ROW_WSTEPS>([&](auto I) __attribute__((always_inline)) {
                 constexpr int i = decltype(I)::value;
-                za[i] = lds_get(A4 + sa[i]);
-                zb[i] = lds_get(B4 + sb[i]);
+                za[i] = lds_get(A4 + sl[i]);
+                zb[i] = lds_get(B4 + (M2 - 1 - sl[i]));
+                zc[i] = lds_get(A4 + (M2 - 1 - sl[i]));
+                zd[i] = lds_get(B4 + sl[i]);
             });
-            static_for<0, ASX_ROW_STEPS>([&](auto I) __attribute__((always_inline)) {
+            static_for<0, ASX_ROW_WSTEPS>([&](auto I) __attribute__((always_inline)) {
                 constexpr int i = decltype(I)::value;
-                const int s = threadIdx.x + i * nthreads;
-                combine_pair(za[i], zb[i], cmul(wA, w2[i]), gk[i], gm[i]);
-                if (s >= M2) sa[i] = -1;
+                const int sx = threadIdx.x + i * nthreads;
+                float2 gk0, gm0, gk1, gm1;
+                combine_pair(za[i], zb[i], cmul(wA, w2a[i]), gk0, gm0); // bin(s) of k1 with bin(s') of m1
+                combine_pair(zc[i], zd[i], cmul(wA, w2b[i]), gk1, gm1); // bin(s') of k1 with bin(s) of m1
+                if (sx < npairs2) {
+                    const int sp = M2 - 1 - sx;
+                    if (sp != sx) {
+                        A4[sx] = make_float4(gk0.x, gk0.y, gm1.x, gm1.y);
+                        A4[sp] = make_float4(gk1.x, gk1.y, gm0.x, gm0.y);
+                    } else { // odd M2: the middle slot is its own partner
+                        A4[sx] = make_float4(gk0.x, gk0.y, gm0.x, gm0.y);
+                    }
+                }
             });
         } else {
+        // Self-paired rows (k1 = 0, M1/2; two blocks per pair): bins pair up inside the row through the
+        // index table.  Every thread first computes its G values into registers (it reads slots other
+        // threads will overwrite), then, after a barrier, writes them.
+        float2 gk[ASX_ROW_STEPS], gm[ASX_ROW_STEPS];
+        int sa[ASX_ROW_STEPS], sb[ASX_ROW_STEPS]; // -1: nothing to write
         static_for<0, ASX_ROW_STEPS>([&](auto I) __attribute__((always_inline)) {
             constexpr int i = decltype(I)::value;
             const int k2 = threadIdx.x + i * nthreads;
             sa[i] = -1; sb[i] = -1;
             gk[i] = make_float2(0.f, 0.f); gm[i] = make_float2(0.f, 0.f);
-            if (k1 == 0) {
+            if (ASX_ABL & 2) {
+            } else if (k1 == 0) {
                 if (k2 == 0) {
                     // DC and Nyquist bins are real: X[0] = Re Z0 + Im Z0, X[M] = Re Z0 - Im Z0
                     const Cx2 z = lds_get(A4);
@@ -526,23 +546,15 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, ASX_ROWS_MIN_WAVES) void k_row
                 }
             }
         });
-        }
-        TwPre pre_i;
         if constexpr (STATIC) pre_i = tw_prefetch_first<S2, true, false>(Li, P.tw2);
         else pre_i = tw_prefetch<false>(PD.st2, PD.st2.nstages - 1, Li, P.tw2);
         __syncthreads();
         static_for<0, ASX_ROW_STEPS>([&](auto I) __attribute__((always_inline)) {
             constexpr int i = decltype(I)::value;
-            if (!self) {
-                if (sa[i] >= 0) {
-                    C2[2 * sa[i]] = gk[i];       // member 0 of slot sa
-                    C2[2 * sb[i] + 1] = gm[i];   // member 1 of slot sb
-                }
-            } else {
-                if (sa[i] >= 0) A4[sa[i]] = make_float4(gk[i].x, gk[i].y, 0.f, 0.f);
-                if (sb[i] >= 0) A4[sb[i]] = make_float4(gm[i].x, gm[i].y, 0.f, 0.f);
-            }
+            if (sa[i] >= 0) A4[sa[i]] = make_float4(gk[i].x, gk[i].y, 0.f, 0.f);
+            if (sb[i] >= 0) A4[sb[i]] = make_float4(gm[i].x, gm[i].y, 0.f, 0.f);
         });
+        }
         __syncthreads();
 
         ASX_STAMP(3);
@@ -738,7 +750,7 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_inv_cols(const AsxDe
     (void)stamp_block;
     ASX_STAMP_AT(2, stamp_block, 0);
     TwPre pre;
-    if constexpr (STATIC) pre = tw_prefetch_first<S1, true, true>(Lc, P.tw1);
+    if constexpr (STATIC) pre = tw_prefetch_first<S1, true, true, true>(Lc, P.tw1);
     else pre = tw_prefetch<true>(PD.st1, PD.st1.nstages - 1, Lc, P.tw1);
     for (int e0 = threadIdx.x; e0 < nelem4; e0 += ASX_COL_LOADS * nthreads) {
         float4 v[ASX_COL_LOADS];
