@@ -76,9 +76,17 @@ void asx_plan_destroy(asx_plan *plan);
  * the float32 maximum is re-evaluated exactly and the reference's rule is applied to the exact values,
  * for up to asx_plan_peak_capacity() such lags per pair (2048..16384 by sample_len; all 2N lags for
  * short tracks).  A pair with more near-ties than that (an all-zero correlation, or a signal periodic
- * in that many lags) keeps the float32 argmax, and the event is counted: *count = number of such pairs
- * since the plan was created.  Synchronises the plan's streams. */
+ * in that many lags) is counted -- asx_plan_peak_overflows(): *count = number of such pairs since the
+ * plan was created -- and
+ *   - the SYNCHRONOUS entry points (asx_xcorr_f64 = cross_correlation(double*), asx_xcorr_batch_f32,
+ *     asx_xcorr_batch_multi, asx_stream_xcorr) take a second look at it with lists that hold all 2N
+ *     lags, so that no candidate limit remains (asx_plan_peak_repairs() counts these; slow: candidates
+ *     x N multiply-adds);
+ *   - the asynchronous device-resident batch (asx_xcorr_batch_f32_dev) keeps the float32 argmax, which
+ *     already is the smallest lag among equal float32 values.
+ * Both getters synchronise the plan's streams. */
 int asx_plan_peak_overflows(asx_plan *plan, uint64_t *count);
+int asx_plan_peak_repairs(asx_plan *plan, uint64_t *count);
 size_t asx_plan_peak_capacity(const asx_plan *plan);
 
 /* Introspection (used by tests, bench and DESIGN.md's numbers). */

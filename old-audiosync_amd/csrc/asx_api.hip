@@ -106,6 +106,17 @@ struct asx_plan {
     } lanes[2];
     int nlanes = 1;   // ASX_LANES=2 enables the second lane (measured: +0..4 %)
     hipEvent_t fork = nullptr;
+    // Second look for pairs whose near-tie list overflowed (lazy; see repair_overflows): lists that hold
+    // every lag of ONE pair
+    struct BigPeak {
+        AsxCand *cand = nullptr;
+        uint32_t *refine_idx = nullptr, *cand_n = nullptr, *refine_n = nullptr;
+        double *refine_val = nullptr;
+        unsigned long long *overflows = nullptr;
+        size_t cap = 0;
+    } big;
+    std::vector<uint32_t> h_cand_n;
+    unsigned long long repaired = 0;   // pairs that took the second look
     // staging for the host-pointer entry points (lazy)
     float *st_src = nullptr, *st_smp = nullptr;
     int64_t *st_lag = nullptr;
@@ -374,6 +385,14 @@ extern "C" int asx_plan_peak_overflows(asx_plan *p, uint64_t *count)
     return 0;
 }
 
+extern "C" int asx_plan_peak_repairs(asx_plan *p, uint64_t *count)
+{
+    if (!p || !count) return fail("asx_plan_peak_repairs: null argument");
+    std::lock_guard<std::mutex> guard(p->lock);
+    *count = p->repaired;
+    return 0;
+}
+
 // diagnostic (not in the public header): the peak-search state of pair `pair` of the last group on lane 0
 extern "C" int asx_plan_debug_peak(asx_plan *p, size_t pair, float *bound2, uint32_t *cand_n, uint32_t *refine_n,
                                    unsigned long long *pairmax, double *vals, uint32_t *idxs, size_t cap)
@@ -478,6 +497,65 @@ static int run_group(asx_plan *p, const float *d_src, const float *d_smp, const 
     return 0;
 }
 
+// Second look at the pairs of the group just run whose near-tie list overflowed (more lags inside the
+// float32 error window than the per-pair list holds: a pure tone of low frequency at a production
+// length has hundreds of thousands).  For each such pair the inverse column pass is run again on its G
+// (still in the lane's workspace) into a list that holds all 2N lags, every listed lag is re-evaluated
+// exactly, and the Pearson pass is redone for the lag that wins: the reference's float64 scan
+// (src/cross_correlation.c:52-67) has no candidate limit, so neither has this path.  It costs
+// candidates x N double-double multiply-adds (about 0.2 s for 400 000 candidates at N = 1 440 000) and
+// needs the host to look at the group's counters, so only the synchronous entry points call it
+// (cross_correlation(double*), the host-array batch, the growing-window stream); the device-resident
+// asynchronous batch counts such pairs instead (asx_plan_peak_overflows).
+template <typename TIn>
+static int repair_overflows(asx_plan *p, int lane, size_t g, const TIn *p_src, const TIn *p_smp,
+                            int64_t *d_lag, double *d_coef, int32_t *d_ret, hipStream_t s)
+{
+    const AsxDev &P = p->dev;
+    asx_plan::Lane &W = p->lanes[lane];
+    const size_t N = p->host.N;
+    if (W.pk.cap >= 2 * N) return 0; // the ordinary list already holds every lag
+    p->h_cand_n.resize(g);
+    HIP_TRY(hipMemcpyAsync(p->h_cand_n.data(), W.pk.cand_n, g * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    for (size_t i = 0; i < g; i++) {
+        if (p->h_cand_n[i] <= W.pk.cap) continue;
+        asx_plan::BigPeak &B = p->big;
+        if (!B.cand) {
+            B.cap = 2 * N;
+            if (dev_alloc(p, &B.cand, B.cap) || dev_alloc(p, &B.refine_idx, B.cap) || dev_alloc(p, &B.refine_val, B.cap) ||
+                dev_alloc(p, &B.cand_n, 1) || dev_alloc(p, &B.refine_n, 1) || dev_alloc(p, &B.overflows, 1))
+                return -1;
+            HIP_TRY(hipMemsetAsync(B.overflows, 0, sizeof(unsigned long long), s));
+        }
+        AsxPeakWs K = W.pk;               // the pair's own norms, bound and (final) float32 maximum ...
+        K.nrm_part += i * 2 * (size_t)P.ntiles;
+        K.bound2 += i;
+        K.pairmax += i;
+        K.cand_n = B.cand_n; K.cand = B.cand; // ... with lists for all 2N lags
+        K.refine_n = B.refine_n; K.refine_idx = B.refine_idx; K.refine_val = B.refine_val;
+        K.overflows = B.overflows;
+        K.cap = (uint32_t)B.cap;
+        HIP_TRY(hipMemsetAsync(B.cand_n, 0, sizeof(uint32_t), s));
+        asx_launch_inv_cols(P, W.ga + i * (size_t)P.M, K, nullptr, 1, s);
+        asx_launch_finalize(P, K, W.seg + i, 1, s);
+        if (sizeof(TIn) == sizeof(float))
+            asx_launch_refine_f32(P, (const float *)p_src + i * 2 * N, (const float *)p_smp + i * N, K, W.seg + i, 1, s, 2048);
+        else
+            asx_launch_refine_f64(P, (const double *)p_src + i * 2 * N, (const double *)p_smp + i * N, K, W.seg + i, 1, s, 2048);
+        double *ps = W.psums + i * ASX_PEARSON_BLOCKS * 6;
+        if (sizeof(TIn) == sizeof(float))
+            asx_launch_pearson_f32((const float *)p_src + i * 2 * N, (const float *)p_smp + i * N, 2 * N, N, P.N,
+                                   W.seg + i, ps, d_lag ? d_lag + i : nullptr, d_coef + i, d_ret ? d_ret + i : nullptr, 1, s);
+        else
+            asx_launch_pearson_f64((const double *)p_src + i * 2 * N, (const double *)p_smp + i * N, 2 * N, N, P.N,
+                                   W.seg + i, ps, d_lag ? d_lag + i : nullptr, d_coef + i, d_ret ? d_ret + i : nullptr, 1, s);
+        HIP_TRY(hipGetLastError());
+        p->repaired++;
+    }
+    return 0;
+}
+
 extern "C" int asx_xcorr_batch_f32_dev(asx_plan *p, const float *d_source, const float *d_sample,
                                        size_t batch, int64_t *d_lag, double *d_coef, int32_t *d_ret,
                                        void *stream)
@@ -561,6 +639,7 @@ extern "C" int asx_xcorr_batch_f32(asx_plan *p, const float *source, const float
         if (run_group<float>(p, p->st_src, p->st_smp, p->st_src, p->st_smp, g, p->st_lag, p->st_coef,
                              p->st_ret, nullptr, s, 0))
             return -1;
+        if (repair_overflows<float>(p, 0, g, p->st_src, p->st_smp, p->st_lag, p->st_coef, p->st_ret, s)) return -1;
         HIP_TRY(hipMemcpyAsync(lag + done, p->st_lag, g * sizeof(int64_t), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipMemcpyAsync(coef + done, p->st_coef, g * sizeof(double), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipMemcpyAsync(ret + done, p->st_ret, g * sizeof(int32_t), hipMemcpyDeviceToHost, s));
@@ -623,6 +702,7 @@ extern "C" int asx_xcorr_f64(asx_plan *p, const double *source, const double *sa
     if (run_group<double>(p, p->st_src, p->st_smp, p->st_src64, p->st_smp64, 1, p->st_lag, p->st_coef,
                           p->st_ret, nullptr, s, 0))
         return -1;
+    if (repair_overflows<double>(p, 0, 1, p->st_src64, p->st_smp64, p->st_lag, p->st_coef, p->st_ret, s)) return -1;
     int64_t h_lag = 0;
     double h_coef = 0;
     int32_t h_ret = -1;
@@ -817,6 +897,7 @@ extern "C" int asx_stream_xcorr(asx_stream *st, size_t sample_len, long *lag, do
     if (run_group<double>(p, st->src32, st->smp32, st->src64, st->smp64, 1, st->d_lag, st->d_coef, st->d_ret,
                           nullptr, s, 0))
         return -1;
+    if (repair_overflows<double>(p, 0, 1, st->src64, st->smp64, st->d_lag, st->d_coef, st->d_ret, s)) return -1;
     int64_t h_lag = 0;
     double h_coef = 0;
     int32_t h_ret = -1;

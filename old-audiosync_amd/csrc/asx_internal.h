@@ -117,9 +117,9 @@ void asx_launch_inv_cols(const AsxDev &P, const float2 *ga, const AsxPeakWs &W, 
                          int npairs, hipStream_t s);
 void asx_launch_finalize(const AsxDev &P, const AsxPeakWs &W, AsxSeg *seg, int npairs, hipStream_t s);
 void asx_launch_refine_f32(const AsxDev &P, const float *src, const float *smp, const AsxPeakWs &W,
-                           AsxSeg *seg, int npairs, hipStream_t s);
+                           AsxSeg *seg, int npairs, hipStream_t s, int dot_blocks = ASX_DOT_BLOCKS);
 void asx_launch_refine_f64(const AsxDev &P, const double *src, const double *smp, const AsxPeakWs &W,
-                           AsxSeg *seg, int npairs, hipStream_t s);
+                           AsxSeg *seg, int npairs, hipStream_t s, int dot_blocks = ASX_DOT_BLOCKS);
 void asx_launch_pearson_f32(const float *src, const float *smp, size_t src_pitch, size_t smp_pitch,
                             uint32_t basis_len, const AsxSeg *seg, double *psums, int64_t *lag,
                             double *coef, int32_t *ret, int npairs, hipStream_t s);

@@ -1490,16 +1490,16 @@ void asx_launch_finalize(const AsxDev &P, const AsxPeakWs &W, AsxSeg *seg, int n
 }
 
 void asx_launch_refine_f32(const AsxDev &P, const float *src, const float *smp, const AsxPeakWs &W,
-                           AsxSeg *seg, int npairs, hipStream_t s)
+                           AsxSeg *seg, int npairs, hipStream_t s, int dot_blocks)
 {
-    hipLaunchKernelGGL(k_refine_dots<float>, dim3(ASX_DOT_BLOCKS, npairs), dim3(ASX_THREADS), 0, s, P.self_dev, src, smp, W);
+    hipLaunchKernelGGL(k_refine_dots<float>, dim3(dot_blocks, npairs), dim3(ASX_THREADS), 0, s, P.self_dev, src, smp, W);
     hipLaunchKernelGGL(k_refine_pick, dim3(npairs), dim3(ASX_THREADS), 0, s, P.self_dev, W, seg);
 }
 
 void asx_launch_refine_f64(const AsxDev &P, const double *src, const double *smp, const AsxPeakWs &W,
-                           AsxSeg *seg, int npairs, hipStream_t s)
+                           AsxSeg *seg, int npairs, hipStream_t s, int dot_blocks)
 {
-    hipLaunchKernelGGL(k_refine_dots<double>, dim3(ASX_DOT_BLOCKS, npairs), dim3(ASX_THREADS), 0, s, P.self_dev, src, smp, W);
+    hipLaunchKernelGGL(k_refine_dots<double>, dim3(dot_blocks, npairs), dim3(ASX_THREADS), 0, s, P.self_dev, src, smp, W);
     hipLaunchKernelGGL(k_refine_pick, dim3(npairs), dim3(ASX_THREADS), 0, s, P.self_dev, W, seg);
 }
 

@@ -135,7 +135,9 @@ def test_float32_error_stays_inside_the_bound(mod, n):
             assert err < 0.5 * bound_rel, (n, name, err, bound_rel)
 
 
-def test_overflow_is_counted_and_keeps_the_float32_rule(mod):
+def test_overflow_is_counted_and_looked_at_again(mod):
+    """the synchronous entry points re-run an overflowing pair with lists for all 2N lags: no candidate limit,
+    like the reference's scan (src/cross_correlation.c:52-67); the asynchronous device batch only counts"""
     n = 48000
     with mod.Plan(n, 2, 0) as plan:
         cap = plan.peak_capacity
@@ -147,9 +149,30 @@ def test_overflow_is_counted_and_keeps_the_float32_rule(mod):
         base = np.array([3, -1, 2, 0, -2, 1, -3, 0], dtype=np.float32)
         per = np.tile(base, 2 * n // 8)
         lag, coef, ret = plan.xcorr_batch_f32(np.stack([src, per]), np.stack([zero, per[:n]]))
-        assert plan.peak_overflows() == 2
+        assert plan.peak_overflows() == 2 and plan.peak_repairs() == 2
+        # the device-resident asynchronous entry: counted, float32 argmax kept (smallest lag among equal keys)
+        import torch
+        d_src = torch.from_numpy(np.stack([src, per])).cuda(); d_smp = torch.from_numpy(np.stack([zero, per[:n]])).cuda()
+        d_lag = torch.zeros(2, dtype=torch.int64, device="cuda"); d_coef = torch.zeros(2, dtype=torch.float64, device="cuda")
+        d_ret = torch.zeros(2, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        plan.xcorr_batch_dev(d_src.data_ptr(), d_smp.data_ptr(), 2, d_lag.data_ptr(), d_coef.data_ptr(), d_ret.data_ptr())
+        assert plan.peak_overflows() == 4 and plan.peak_repairs() == 2
+        assert int(d_lag[1]) % 8 == 0 and int(d_ret[0]) == -1
     assert int(ret[0]) == -1 and int(lag[0]) == 0          # like the reference: index 0, NaN coefficient
-    assert int(ret[1]) == 0 and int(lag[1]) % 8 == 0 and coef[1] == 1.0
+    # 12 000 exactly tied peaks (every 8th lag): the exact values tie, the smallest lag wins as in a sequential scan
+    assert int(ret[1]) == 0 and int(lag[1]) == 0 and coef[1] == 1.0
+
+
+def test_second_look_through_the_reference_api(hostlib):
+    """cross_correlation(double*) on a pair whose near-tie list overflows (source periodic in 16 frames at
+    N = 96 000: 12 000 exact ties > 2 048 list entries): the second look resolves them exactly"""
+    n = 96000
+    base = np.random.default_rng(11).integers(-5, 6, 16).astype(np.float64)
+    src = np.tile(base, 2 * n // 16)
+    smp = np.roll(src, -5)[:n].copy()           # sample = source advanced by 5 frames: ties at 5, 21, 37, ...
+    ret, lag, coef = call_cross_correlation(hostlib, src, smp)
+    assert (ret, lag) == (0, 5) and coef == 1.0
 
 
 def test_many_ties_below_capacity_are_all_resolved(mod):
