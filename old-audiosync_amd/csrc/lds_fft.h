@@ -25,6 +25,10 @@
 
 #include <type_traits>
 
+#ifndef ASX_EXP_UNITTW
+#define ASX_EXP_UNITTW 0 /* experiment (wrong results): no stage twiddles at all, -25 % VALU work */
+#endif
+
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b)
 {
@@ -585,7 +589,7 @@ __device__ __forceinline__ void lds_stage_wavepair(float4 *lds, const LdsLayout 
             if (active) {
                 Cx2 v[R];
                 static_for<0, R>([&](auto T) __attribute__((always_inline)) { v[T] = lds_get(p + T * step); });
-                if constexpr (K.q == 1) {
+                if constexpr (K.q == 1 || ASX_EXP_UNITTW) {
                     Bfly<R, INV>::run(v);
                 } else {
                     float2 w1 = pre.w1, w4 = pre.w4;
@@ -676,7 +680,7 @@ __device__ __forceinline__ TwPre lds_fft_static_steps(float4 *lds, const LdsLayo
         } else {
             constexpr StageK K = S::stage(i);
             const TwPre next = tw_prefetch_exec<S, inext, GFAST, INV, HEAD>(L, tw);
-            lds_stage<K.R, INV, GFAST, K.q == 1>(lds, K, L, tw, pre);
+            lds_stage<K.R, INV, GFAST, K.q == 1 || ASX_EXP_UNITTW>(lds, K, L, tw, pre);
             pre = next;
             __syncthreads();
         }
