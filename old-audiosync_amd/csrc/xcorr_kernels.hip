@@ -52,6 +52,21 @@
 #ifndef ASX_ABL
 #define ASX_ABL 0
 #endif
+// Experiment: ASX_NT & 1 non-temporal row loads in k_rows, & 2 non-temporal row stores, & 4 non-temporal loads in the Pearson pass
+#ifndef ASX_NT
+#define ASX_NT 4 // Pearson reads its inputs once: non-temporal loads, 0.213 -> 0.201 ms; the row kernel got slower with them
+#endif
+typedef float asx_f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 asx_ld16(const float2 *p, bool nt)
+{
+    if (nt) { const asx_f4v v = __builtin_nontemporal_load(reinterpret_cast<const asx_f4v *>(p)); return make_float4(v.x, v.y, v.z, v.w); }
+    return *reinterpret_cast<const float4 *>(p);
+}
+__device__ __forceinline__ void asx_st16(float2 *p, float4 v, bool nt)
+{
+    if (nt) { asx_f4v w = { v.x, v.y, v.z, v.w }; __builtin_nontemporal_store(w, reinterpret_cast<asx_f4v *>(p)); }
+    else *reinterpret_cast<float4 *>(p) = v;
+}
 #ifndef ASX_ROWS_MIN_WAVES
 #define ASX_ROWS_MIN_WAVES 4   // k_rows fits 128 VGPRs (92-119 by variant): four blocks per CU, which is also what its LDS allows
 #endif
@@ -377,11 +392,11 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, ASX_ROWS_MIN_WAVES) void k_row
                     const int q = threadIdx.x + decltype(I)::value * nthreads;
                     LW.xa[I] = LW.ya[I] = LW.xb[I] = LW.yb[I] = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (q < half) {
-                        LW.xa[I] = *reinterpret_cast<const float4 *>(gx + (size_t)pa * M2 + 2 * q);
-                        LW.ya[I] = *reinterpret_cast<const float4 *>(gy + (size_t)pa * M2 + 2 * q);
+                        LW.xa[I] = asx_ld16(gx + (size_t)pa * M2 + 2 * q, ASX_NT & 1);
+                        LW.ya[I] = asx_ld16(gy + (size_t)pa * M2 + 2 * q, ASX_NT & 1);
                         if (!self) {
-                            LW.xb[I] = *reinterpret_cast<const float4 *>(gx + (size_t)pb * M2 + 2 * q);
-                            LW.yb[I] = *reinterpret_cast<const float4 *>(gy + (size_t)pb * M2 + 2 * q);
+                            LW.xb[I] = asx_ld16(gx + (size_t)pb * M2 + 2 * q, ASX_NT & 1);
+                            LW.yb[I] = asx_ld16(gy + (size_t)pb * M2 + 2 * q, ASX_NT & 1);
                         }
                     }
                 });
@@ -591,9 +606,9 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, ASX_ROWS_MIN_WAVES) void k_row
                     const float2 wa1 = cmul(wa0, wk1), wb1 = cmul(wb0, wm1);
                     const Cx2 h0 = mul2c(g0[i], Cx2{ v2f{ wa0.x, wb0.x }, v2f{ wa0.y, wb0.y } });
                     const Cx2 h1 = mul2c(g1[i], Cx2{ v2f{ wa1.x, wb1.x }, v2f{ wa1.y, wb1.y } });
-                    *reinterpret_cast<float4 *>(go + (size_t)pa * M2 + 2 * q) = make_float4(h0.re.x, h0.im.x, h1.re.x, h1.im.x);
+                    asx_st16(go + (size_t)pa * M2 + 2 * q, make_float4(h0.re.x, h0.im.x, h1.re.x, h1.im.x), ASX_NT & 2);
                     if (!self)
-                        *reinterpret_cast<float4 *>(go + (size_t)pb * M2 + 2 * q) = make_float4(h0.re.y, h0.im.y, h1.re.y, h1.im.y);
+                        asx_st16(go + (size_t)pb * M2 + 2 * q, make_float4(h0.re.y, h0.im.y, h1.re.y, h1.im.y), ASX_NT & 2);
                 }
             });
         } else {
@@ -1154,7 +1169,8 @@ __global__ __launch_bounds__(ASX_THREADS) void k_pearson_partial(const TIn *__re
     // so the vector type only promises element alignment), then the few elements that are left
     typedef TIn vec4u __attribute__((ext_vector_type(4), aligned(sizeof(TIn))));
     for (; i + 3 < hi; i += 4u * ASX_THREADS) {
-        const vec4u a = *reinterpret_cast<const vec4u *>(x + i), b = *reinterpret_cast<const vec4u *>(y + i);
+        const vec4u a = (ASX_NT & 4) ? __builtin_nontemporal_load(reinterpret_cast<const vec4u *>(x + i)) : *reinterpret_cast<const vec4u *>(x + i);
+        const vec4u b = (ASX_NT & 4) ? __builtin_nontemporal_load(reinterpret_cast<const vec4u *>(y + i)) : *reinterpret_cast<const vec4u *>(y + i);
         add((double)a.x, (double)b.x);
         add((double)a.y, (double)b.y);
         add((double)a.z, (double)b.z);
