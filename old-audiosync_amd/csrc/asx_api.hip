@@ -106,15 +106,6 @@ struct asx_plan {
     } lanes[2];
     int nlanes = 1;   // ASX_LANES=2 enables the second lane (measured: +0..4 %)
     hipEvent_t fork = nullptr;
-    // Pearson pipeline (asx_xcorr_batch_f32_dev, batches of two or more groups): the Pearson pass of
-    // group i -- a pure HBM stream that needs no LDS and few registers -- runs on a side stream while
-    // k_rows of group i+1, which leaves the HBM idle and has wave slots and registers to spare, runs on
-    // the caller's stream.  Two sets of segment / partial-sum buffers alternate between the groups.
-    int pipe_groups = 1;          // ASX_PIPE_GROUPS: a plan's max_batch is cut into this many launch groups
-    hipStream_t side = nullptr;
-    hipEvent_t ev_fin[2] = { nullptr, nullptr }, ev_pe[2] = { nullptr, nullptr }, ev_fwd = nullptr;
-    AsxSeg *seg_alt = nullptr;    // slot 1 (slot 0 = lanes[0].seg)
-    double *psums_alt = nullptr;
     // Second look for pairs whose near-tie list overflowed (lazy; see repair_overflows): lists that hold
     // every lag of ONE pair
     struct BigPeak {
@@ -198,9 +189,6 @@ static int plan_init(asx_plan *p, size_t N, size_t max_batch, const char *split)
     if (g > 65535) g = 65535; // grid.y / grid.z limit
     if (max_batch < 1) max_batch = 1;
     if (g > max_batch) g = max_batch;
-    if (const char *e = getenv("ASX_PIPE_GROUPS")) p->pipe_groups = std::max(1, atoi(e));
-    if (p->pipe_groups > 1 && max_batch >= (size_t)8 * p->pipe_groups)
-        g = std::min(g, (max_batch + p->pipe_groups - 1) / p->pipe_groups);
     p->group = g;
     if (const char *e = getenv("ASX_LANES")) p->nlanes = atoi(e) == 2 ? 2 : 1;
     // candidate capacity per pair of the peak refinement (asx_internal.h): all 2N lags for short
@@ -223,13 +211,6 @@ static int plan_init(asx_plan *p, size_t N, size_t max_batch, const char *split)
         HIP_TRY(hipEventCreateWithFlags(&ln.done, hipEventDisableTiming));
     }
     HIP_TRY(hipEventCreateWithFlags(&p->fork, hipEventDisableTiming));
-    if (dev_alloc(p, &p->seg_alt, g) || dev_alloc(p, &p->psums_alt, g * ASX_PEARSON_BLOCKS * 6)) return -1;
-    HIP_TRY(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
-    for (int i = 0; i < 2; i++) {
-        HIP_TRY(hipEventCreateWithFlags(&p->ev_fin[i], hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&p->ev_pe[i], hipEventDisableTiming));
-    }
-    HIP_TRY(hipEventCreateWithFlags(&p->ev_fwd, hipEventDisableTiming));
     d.stamps = nullptr;
     d.stamp_kernel = 0;
     if (const char *e = getenv("ASX_STAMPS")) {
@@ -366,12 +347,6 @@ extern "C" void asx_plan_destroy(asx_plan *p)
         if (ln.done) (void)hipEventDestroy(ln.done);
     }
     if (p->fork) (void)hipEventDestroy(p->fork);
-    if (p->side) { (void)hipStreamSynchronize(p->side); (void)hipStreamDestroy(p->side); }
-    for (int i = 0; i < 2; i++) {
-        if (p->ev_fin[i]) (void)hipEventDestroy(p->ev_fin[i]);
-        if (p->ev_pe[i]) (void)hipEventDestroy(p->ev_pe[i]);
-    }
-    if (p->ev_fwd) (void)hipEventDestroy(p->ev_fwd);
     for (hipEvent_t ev : p->ev) (void)hipEventDestroy(ev);
     for (void *a : p->allocs) (void)hipFree(a);
     (void)hipSetDevice(prev);
@@ -489,60 +464,37 @@ static int prof_mark(asx_plan *p, hipStream_t s, size_t slot)
     return 0;
 }
 
-// One group: g <= plan->group pairs, inputs device resident.  TIn selects the input type of the exact
-// re-evaluation and of the Pearson pass.  Two halves so that the Pearson pass can go to another stream:
-// the transforms with the peak search (segments into `seg`), then the Pearson pass over the segments.
+// one group: g <= plan->group pairs, inputs device resident.  TIn selects the Pearson input type.
 template <typename TIn>
-static int run_group_peak(asx_plan *p, const float *d_src, const float *d_smp, const TIn *p_src,
-                          const TIn *p_smp, size_t g, float *d_r, hipStream_t s, size_t group_index, int lane,
-                          AsxSeg *seg, hipEvent_t after_fwd = nullptr)
+static int run_group(asx_plan *p, const float *d_src, const float *d_smp, const TIn *p_src,
+                     const TIn *p_smp, size_t g, int64_t *d_lag, double *d_coef, int32_t *d_ret,
+                     float *d_r, hipStream_t s, size_t group_index, int lane = 0)
 {
     const AsxDev &P = p->dev;
     asx_plan::Lane &W = p->lanes[lane];
     const size_t e0 = group_index * 6;
     if (prof_mark(p, s, e0 + 0)) return -1;
     asx_launch_fwd_cols(P, d_src, d_smp, W.zxa, W.zya, W.pk, (int)g, s);
-    if (after_fwd) HIP_TRY(hipEventRecord(after_fwd, s));
     if (prof_mark(p, s, e0 + 1)) return -1;
     asx_launch_rows(P, W.zxa, W.zya, W.ga, W.pk, (int)g, s);
     if (prof_mark(p, s, e0 + 2)) return -1;
     asx_launch_inv_cols(P, W.ga, W.pk, d_r, (int)g, s);
     if (prof_mark(p, s, e0 + 3)) return -1;
-    asx_launch_finalize(P, W.pk, seg, (int)g, s);
+    asx_launch_finalize(P, W.pk, W.seg, (int)g, s);
     if (sizeof(TIn) == sizeof(float))
-        asx_launch_refine_f32(P, (const float *)p_src, (const float *)p_smp, W.pk, seg, (int)g, s);
+        asx_launch_refine_f32(P, (const float *)p_src, (const float *)p_smp, W.pk, W.seg, (int)g, s);
     else
-        asx_launch_refine_f64(P, (const double *)p_src, (const double *)p_smp, W.pk, seg, (int)g, s);
+        asx_launch_refine_f64(P, (const double *)p_src, (const double *)p_smp, W.pk, W.seg, (int)g, s);
     if (prof_mark(p, s, e0 + 4)) return -1;
-    HIP_TRY(hipGetLastError());
-    return 0;
-}
-
-template <typename TIn>
-static int run_group_pearson(asx_plan *p, const TIn *p_src, const TIn *p_smp, size_t g, int64_t *d_lag,
-                             double *d_coef, int32_t *d_ret, hipStream_t s, size_t group_index,
-                             const AsxSeg *seg, double *psums)
-{
-    const AsxDev &P = p->dev;
     if (sizeof(TIn) == sizeof(float))
         asx_launch_pearson_f32((const float *)p_src, (const float *)p_smp, 2 * (size_t)P.N, P.N, P.N,
-                               seg, psums, d_lag, d_coef, d_ret, (int)g, s);
+                               W.seg, W.psums, d_lag, d_coef, d_ret, (int)g, s);
     else
         asx_launch_pearson_f64((const double *)p_src, (const double *)p_smp, 2 * (size_t)P.N, P.N, P.N,
-                               seg, psums, d_lag, d_coef, d_ret, (int)g, s);
-    if (prof_mark(p, s, group_index * 6 + 5)) return -1;
+                               W.seg, W.psums, d_lag, d_coef, d_ret, (int)g, s);
+    if (prof_mark(p, s, e0 + 5)) return -1;
     HIP_TRY(hipGetLastError());
     return 0;
-}
-
-template <typename TIn>
-static int run_group(asx_plan *p, const float *d_src, const float *d_smp, const TIn *p_src,
-                     const TIn *p_smp, size_t g, int64_t *d_lag, double *d_coef, int32_t *d_ret,
-                     float *d_r, hipStream_t s, size_t group_index, int lane = 0)
-{
-    asx_plan::Lane &W = p->lanes[lane];
-    if (run_group_peak<TIn>(p, d_src, d_smp, p_src, p_smp, g, d_r, s, group_index, lane, W.seg)) return -1;
-    return run_group_pearson<TIn>(p, p_src, p_smp, g, d_lag, d_coef, d_ret, s, group_index, W.seg, W.psums);
 }
 
 // Second look at the pairs of the group just run whose near-tie list overflowed (more lags inside the
@@ -620,52 +572,11 @@ extern "C" int asx_xcorr_batch_f32_dev(asx_plan *p, const float *d_source, const
     const bool overlap = (p->nlanes == 2) && !p->profiling && batch >= 8;
     size_t chunk = p->group;
     if (overlap && batch < 2 * chunk) chunk = (batch + 1) / 2;
-    const size_t ngroups = (batch + chunk - 1) / chunk;
-    size_t gi = 0;
-    if (!overlap && !p->profiling && ngroups >= 2 && p->pipe_groups > 1) {
-        // Pearson pipeline: group i's Pearson pass on the side stream, started once k_fwd_cols of group
-        // i+1 (which competes for the HBM) has finished, i.e. beside k_rows of group i+1.
-        const float *src = d_source, *smp = d_sample;
-        for (size_t done = 0; done < batch; done += chunk, gi++) {
-            const size_t g = std::min(chunk, batch - done);
-            const int slot = (int)(gi & 1);
-            AsxSeg *seg = slot ? p->seg_alt : p->lanes[0].seg;
-            if (gi >= 2) HIP_TRY(hipStreamWaitEvent(s, p->ev_pe[slot], 0)); // the slot's previous Pearson pass is done
-            if (run_group_peak<float>(p, src + done * 2 * N, smp + done * N, src + done * 2 * N, smp + done * N, g,
-                                      nullptr, s, gi, 0, seg, gi >= 1 ? p->ev_fwd : nullptr))
-                return -1;
-            HIP_TRY(hipEventRecord(p->ev_fin[slot], s));
-            if (gi >= 1) {
-                // Pearson of the previous group: after its segments exist and after this group's k_fwd_cols
-                const size_t pd = done - chunk;
-                const int ps = slot ^ 1;
-                HIP_TRY(hipStreamWaitEvent(p->side, p->ev_fin[ps], 0));
-                HIP_TRY(hipStreamWaitEvent(p->side, p->ev_fwd, 0));
-                if (run_group_pearson<float>(p, src + pd * 2 * N, smp + pd * N, chunk, d_lag ? d_lag + pd : nullptr,
-                                             d_coef + pd, d_ret ? d_ret + pd : nullptr, p->side, gi - 1,
-                                             ps ? p->seg_alt : p->lanes[0].seg, ps ? p->psums_alt : p->lanes[0].psums))
-                    return -1;
-                HIP_TRY(hipEventRecord(p->ev_pe[ps], p->side));
-            }
-        }
-        {   // the last group's Pearson pass has nothing to hide behind
-            const size_t last = gi - 1, pd = last * chunk;
-            const int ps = (int)(last & 1);
-            if (run_group_pearson<float>(p, src + pd * 2 * N, smp + pd * N, batch - pd, d_lag ? d_lag + pd : nullptr,
-                                         d_coef + pd, d_ret ? d_ret + pd : nullptr, s, last,
-                                         ps ? p->seg_alt : p->lanes[0].seg, ps ? p->psums_alt : p->lanes[0].psums))
-                return -1;
-            // join: everything the side stream was given (its work is in order: the last record covers all)
-            HIP_TRY(hipEventRecord(p->fork, p->side));
-            HIP_TRY(hipStreamWaitEvent(s, p->fork, 0));
-        }
-        prof_end_call(p, gi);
-        return 0;
-    }
     if (overlap) {
         HIP_TRY(hipEventRecord(p->fork, s));
         for (int l = 0; l < 2; l++) HIP_TRY(hipStreamWaitEvent(p->lanes[l].stream, p->fork, 0));
     }
+    size_t gi = 0;
     for (size_t done = 0; done < batch; done += chunk, gi++) {
         const size_t g = std::min(chunk, batch - done);
         const int lane = overlap ? (int)(gi & 1) : 0;
