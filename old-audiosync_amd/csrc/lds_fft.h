@@ -411,10 +411,16 @@ template <int R> __device__ __forceinline__ void stage_twiddles_from(float2 w1, 
 // pos0 + T*q of transform pair g -- the outputs stay in registers and LDS keeps the stage's INPUT (the
 // peak search of k_inv_cols consumes the last inverse stage this way: r never reaches LDS either).
 struct NoSink {};
+// Source: where a butterfly's R inputs come from.  NoSource = read from their slots.  Any other type is
+// called as src(std::integral_constant<int, R>{}, v, g, pos0, q) and fills v[T] with element pos0 + T*q of
+// transform pair g (k_inv_cols feeds its first stage straight from HBM this way: the tile never makes
+// the LDS write + read + barrier of a separate fill phase).
+struct NoSource {};
 
-template <int R, bool INV, bool GFAST, bool UNIT_TW, class Sink = NoSink>
+template <int R, bool INV, bool GFAST, bool UNIT_TW, class Sink = NoSink, class Source = NoSource>
 __device__ __forceinline__ void lds_stage(float4 *lds, const StageK K, const LdsLayout &L,
-                                          const float2 *__restrict__ tw, TwPre pre, Sink &&sink = Sink{})
+                                          const float2 *__restrict__ tw, TwPre pre, Sink &&sink = Sink{},
+                                          Source &&source = Source{})
 {
     const int ns = K.ns, q = K.q, nbf = K.nbf, twmul = K.twmul;
     const float inv_q = K.inv_q, inv_nbf = K.inv_nbf;
@@ -441,7 +447,10 @@ __device__ __forceinline__ void lds_stage(float4 *lds, const StageK K, const Lds
         float4 *p = lds + g * L.group_stride + (b * ns + j) * L.elem_stride;
 #endif
         Cx2 v[R];
-        static_for<0, R>([&](auto T) __attribute__((always_inline)) { v[T] = lds_get(p + T * step); });
+        if constexpr (std::is_same<typename std::decay<Source>::type, NoSource>::value)
+            static_for<0, R>([&](auto T) __attribute__((always_inline)) { v[T] = lds_get(p + T * step); });
+        else
+            source(std::integral_constant<int, R>{}, v, g, b * ns + j, q);
         if constexpr (UNIT_TW) {
             Bfly<R, INV>::run(v);
         } else {
@@ -660,11 +669,11 @@ __device__ __forceinline__ TwPre tw_prefetch_first(const LdsLayout &L, const flo
 
 // Runs the stages [FIRST_STEP, FIRST_STEP + NSTEPS) of the execution order (forward: stage = step;
 // inverse: stage = nstages - 1 - step), each followed by a barrier; returns the prefetch of the next step.
-template <class S, bool INV, bool GFAST, int NSTEPS, bool HEAD = false>
+template <class S, bool INV, bool GFAST, int NSTEPS, bool HEAD = false, int FIRST = 0>
 __device__ __forceinline__ TwPre lds_fft_static_steps(float4 *lds, const LdsLayout &L, const float2 *__restrict__ tw, TwPre pre)
 {
     constexpr int WPI = wave_pair_index<S, INV, HEAD, GFAST>();
-    static_for<0, NSTEPS>([&](auto I) __attribute__((always_inline)) {
+    static_for<FIRST, NSTEPS>([&](auto I) __attribute__((always_inline)) {
         constexpr int i = INV ? S::nstages - 1 - decltype(I)::value : decltype(I)::value;
         constexpr int inext = INV ? i - 1 : i + 1;
         constexpr bool second_of_pair = WPI >= 0 && (INV ? i == WPI : i == WPI + 1);
@@ -744,6 +753,22 @@ __device__ __forceinline__ TwPre lds_fft_static_head(float4 *lds, const LdsLayou
 {
     // HEAD: the stage left for lds_last_stage_static is never half of a wave pair (wave_pair_index)
     return lds_fft_static_steps<S, INV, GFAST, S::nstages - 1, true>(lds, L, tw, pre);
+}
+// The head with its FIRST stage fed by `source` instead of LDS (block-wide stage, never a wave pair: GFAST
+// kernels have none); the stage writes its outputs to LDS, so the caller needs no fill phase and no barrier
+// before it.  Returns the prefetch of the last stage like lds_fft_static_head.
+template <class S, bool INV, bool GFAST, class Source>
+__device__ __forceinline__ TwPre lds_fft_static_head_fed(float4 *lds, const LdsLayout &L, const float2 *__restrict__ tw, TwPre pre,
+                                                         Source &&source)
+{
+    static_assert(wave_pair_index<S, INV, true, GFAST>() < 0, "fed first stage with wave pairs is not supported");
+    static_assert(S::nstages >= 2, "needs a last stage of its own");
+    constexpr int i0 = INV ? S::nstages - 1 : 0, i1 = INV ? i0 - 1 : i0 + 1;
+    constexpr StageK K = S::stage(i0);
+    const TwPre next = tw_prefetch_exec<S, i1, GFAST, INV, true>(L, tw);
+    lds_stage<K.R, INV, GFAST, K.q == 1>(lds, K, L, tw, pre, NoSink{}, source);
+    __syncthreads();
+    return lds_fft_static_steps<S, INV, GFAST, S::nstages - 1, true, 1>(lds, L, tw, next);
 }
 template <class S, bool INV, bool GFAST, class Sink>
 __device__ __forceinline__ void lds_last_stage_static(float4 *lds, const LdsLayout &L, const float2 *__restrict__ tw, TwPre pre,

@@ -767,6 +767,30 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_inv_cols(const AsxDe
     TwPre pre;
     if constexpr (STATIC) pre = tw_prefetch_first<S1, true, true, true>(Lc, P.tw1);
     else pre = tw_prefetch<true>(PD.st1, PD.st1.nstages - 1, Lc, P.tw1);
+#ifndef ASX_INV_FED
+#define ASX_INV_FED 1 // first inverse stage fed straight from HBM (compile-time schedules, full tiles)
+#endif
+    TwPre pre_last;
+    bool filled = false;
+    if constexpr (STATIC && ASX_INV_FED) {
+        if (even && (c0 + T <= M2)) { // block-uniform: full tile
+            // No fill phase: the first stage to run (innermost, 10 consecutive rows per butterfly) takes its
+            // inputs from HBM -- the thread's loads are all in flight together, as in the fill loop -- and writes
+            // its outputs to LDS: one LDS write + read pass and one barrier less per tile.
+            ASX_STAMP_AT(2, stamp_block, 1);
+            pre_last = lds_fft_static_head_fed<S1, true, true>(lds4, Lc, P.tw1, pre,
+                [&](auto RC, auto &v, int g, int pos0, int q) __attribute__((always_inline)) {
+                    const float2 *col = in + (size_t)pos0 * M2 + c0 + 2 * g;
+                    static_for<0, decltype(RC)::value>([&](auto TT) __attribute__((always_inline)) {
+                        constexpr int t = decltype(TT)::value;
+                        const float4 x = *reinterpret_cast<const float4 *>(col + (size_t)(t * q) * M2);
+                        v[t] = Cx2{ v2f{ x.x, x.z }, v2f{ x.y, x.w } };
+                    });
+                });
+            filled = true;
+        }
+    }
+    if (!filled) {
     for (int e0 = threadIdx.x; e0 < nelem4; e0 += ASX_COL_LOADS * nthreads) {
         float4 v[ASX_COL_LOADS];
         static_for<0, ASX_COL_LOADS>([&](auto I) __attribute__((always_inline)) {
@@ -796,9 +820,9 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_inv_cols(const AsxDe
     ASX_STAMP_AT(2, stamp_block, 1);
     // every inverse stage but the last: the last one's outputs are consumed from registers below
     // (r reaches neither HBM nor LDS; LDS keeps that stage's input, so the stage can be run again)
-    TwPre pre_last;
     if constexpr (STATIC) pre_last = lds_fft_static_head<S1, true, true>(lds4, Lc, P.tw1, pre);
     else pre_last = lds_fft_head<MAXR, true, true>(lds4, PD.st1, Lc, P.tw1, pre);
+    }
     ASX_STAMP_AT(2, stamp_block, 2);
 
     // The pair's running maximum so far (other tiles publish theirs with atomicMax below) and the width
