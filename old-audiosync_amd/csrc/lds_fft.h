@@ -770,6 +770,20 @@ __device__ __forceinline__ TwPre lds_fft_static_head_fed(float4 *lds, const LdsL
     __syncthreads();
     return lds_fft_static_steps<S, INV, GFAST, S::nstages - 1, true, 1>(lds, L, tw, next);
 }
+// Whole transform with its first stage fed by `source` (k_fwd_cols: the tile goes from HBM straight into
+// the first butterflies).  Ends with a barrier like lds_fft_static.
+template <class S, bool INV, bool GFAST, class Source>
+__device__ __forceinline__ void lds_fft_static_fed(float4 *lds, const LdsLayout &L, const float2 *__restrict__ tw, TwPre pre,
+                                                   Source &&source)
+{
+    static_assert(wave_pair_index<S, INV, false, GFAST>() < 0, "fed first stage with wave pairs is not supported");
+    constexpr int i0 = INV ? S::nstages - 1 : 0, i1 = INV ? i0 - 1 : i0 + 1;
+    constexpr StageK K = S::stage(i0);
+    const TwPre next = tw_prefetch_exec<S, i1, GFAST, INV, false>(L, tw);
+    lds_stage<K.R, INV, GFAST, K.q == 1>(lds, K, L, tw, pre, NoSink{}, source);
+    __syncthreads();
+    (void)lds_fft_static_steps<S, INV, GFAST, S::nstages, false, 1>(lds, L, tw, next);
+}
 template <class S, bool INV, bool GFAST, class Sink>
 __device__ __forceinline__ void lds_last_stage_static(float4 *lds, const LdsLayout &L, const float2 *__restrict__ tw, TwPre pre,
                                                       Sink &&sink)

@@ -206,6 +206,36 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_fwd_cols(const AsxDe
     // sum of squares of everything this block loads: |source|^2 and |sample|^2 (the scale of the
     // float32 error bound of the peak search) come out of the pass that reads the inputs anyway
     float ss = 0.f;
+#ifndef ASX_FWD_FED
+#define ASX_FWD_FED 0 // experiment: first forward stage fed straight from HBM; measured 2 % SLOWER (1.07 -> 1.09 ms), unlike k_inv_cols
+#endif
+    bool transformed = false;
+    if constexpr (STATIC && ASX_FWD_FED) {
+        if (fast) { // block-uniform
+            // No fill phase: the first stage (legs M1/R rows apart) takes its inputs from HBM -- all of the
+            // thread's loads in flight together; rows in the zero padding are not loaded (the sample: the upper
+            // half of the legs) -- and writes its outputs to LDS: one LDS write + read pass and one barrier less.
+            ASX_STAMP_AT(1, stamp_block, 1);
+            lds_fft_static_fed<S1, false, true>(lds4, Lc, P.tw1, pre,
+                [&](auto RC, auto &v, int g, int pos0, int q) __attribute__((always_inline)) {
+                    const float *col = in + 2 * ((size_t)pos0 * M2 + c0 + 2 * g);
+                    float4 x[decltype(RC)::value];
+                    static_for<0, decltype(RC)::value>([&](auto TT) __attribute__((always_inline)) {
+                        constexpr int t = decltype(TT)::value;
+                        x[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (pos0 + t * q < data_rows) x[t] = *reinterpret_cast<const float4 *>(col + 2 * (size_t)(t * q) * M2);
+                    });
+                    static_for<0, decltype(RC)::value>([&](auto TT) __attribute__((always_inline)) {
+                        constexpr int t = decltype(TT)::value;
+                        ss = fmaf(x[t].x, x[t].x, fmaf(x[t].y, x[t].y, fmaf(x[t].z, x[t].z, fmaf(x[t].w, x[t].w, ss))));
+                        v[t] = Cx2{ v2f{ x[t].x, x[t].z }, v2f{ x[t].y, x[t].w } };
+                    });
+                });
+            // the norms: every barrier of the transform lies between these writes and the read below
+            transformed = true;
+        }
+    }
+    if (!transformed) {
     for (int e0 = threadIdx.x; e0 < nelem4; e0 += ASX_COL_LOADS * nthreads) {
         float4 v[ASX_COL_LOADS];
         if (fast) {
@@ -246,18 +276,25 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_fwd_cols(const AsxDe
             }
         });
     }
+    }
     ss = wave_sum_f32(ss);
+    if (transformed) {
+        // the transform has ended with a barrier; publish the wave sums behind one more
+        if ((threadIdx.x & 63) == 0) nrm_red[threadIdx.x >> 6] = ss;
+    } else {
     if ((threadIdx.x & 63) == 0) nrm_red[threadIdx.x >> 6] = ss;
     __syncthreads();
+    ASX_STAMP_AT(1, stamp_block, 1);
+    if constexpr (STATIC) lds_fft_static<S1, false, true>(lds4, Lc, P.tw1, pre);
+    else lds_fft<MAXR, false, true>(lds4, PD.st1, Lc, P.tw1, pre);
+    }
+    ASX_STAMP_AT(1, stamp_block, 2);
+    if (transformed) __syncthreads(); // nrm_red written after the transform (block-uniform branch)
     if (threadIdx.x == 0) {
         float t = nrm_red[0];
         for (int w = 1; w < (nthreads + 63) >> 6; w++) t += nrm_red[w];
         nrm_part[(pair * 2 + blockIdx.y) * (size_t)P.ntiles + tile] = t;
     }
-    ASX_STAMP_AT(1, stamp_block, 1);
-    if constexpr (STATIC) lds_fft_static<S1, false, true>(lds4, Lc, P.tw1, pre);
-    else lds_fft<MAXR, false, true>(lds4, PD.st1, Lc, P.tw1, pre);
-    ASX_STAMP_AT(1, stamp_block, 2);
 
     // slot p1 holds frequency k1 = k1_of_pos1[p1] and stays in that slot in HBM; the
     // four-step twiddle w_M^(k1*j2) is applied by k_rows, where k1 is block-uniform.
