@@ -776,8 +776,9 @@ template <class S, bool INV, bool GFAST, class Source>
 __device__ __forceinline__ void lds_fft_static_fed(float4 *lds, const LdsLayout &L, const float2 *__restrict__ tw, TwPre pre,
                                                    Source &&source)
 {
-    static_assert(wave_pair_index<S, INV, false, GFAST>() < 0, "fed first stage with wave pairs is not supported");
+    constexpr int WPI = wave_pair_index<S, INV, false, GFAST>();
     constexpr int i0 = INV ? S::nstages - 1 : 0, i1 = INV ? i0 - 1 : i0 + 1;
+    static_assert(WPI < 0 || (i0 != WPI && i0 != WPI + 1), "the fed stage must be a block-wide stage");
     constexpr StageK K = S::stage(i0);
     const TwPre next = tw_prefetch_exec<S, i1, GFAST, INV, false>(L, tw);
     lds_stage<K.R, INV, GFAST, K.q == 1>(lds, K, L, tw, pre, NoSink{}, source);

@@ -418,7 +418,17 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, ASX_ROWS_MIN_WAVES) void k_row
         const int half = M2 >> 1; // wide: a thread owns the element pairs q = t + nthreads*i, j2 = 2q, 2q+1
         RowRegs L;
         RowRegsWide LW;
-        {
+#ifndef ASX_ROWS_FED
+#define ASX_ROWS_FED 0 // experiment: first forward row stage fed straight from HBM; no difference [measured 1.18-1.20 ms both], +8 VGPRs
+#endif
+        bool fed = false; // block-uniform
+        if constexpr (STATIC && ASX_ROWS_FED) fed = !self;
+#ifdef ASX_EXP_PAIRMOD
+        const float2 *gxf = zxa + (size_t)(pair % ASX_EXP_PAIRMOD) * M, *gyf = zya + (size_t)(pair % ASX_EXP_PAIRMOD) * M;
+#else
+        const float2 *gxf = zxa + (size_t)pair * M, *gyf = zya + (size_t)pair * M;
+#endif
+        if (!fed) {
 #ifdef ASX_EXP_PAIRMOD /* experiment (wrong results): the intermediates of all pairs fall on those of the first ASX_EXP_PAIRMOD pairs (Infinity-Cache resident) */
             const float2 *gx = zxa + (size_t)(pair % ASX_EXP_PAIRMOD) * M, *gy = zya + (size_t)(pair % ASX_EXP_PAIRMOD) * M;
 #else
@@ -471,7 +481,43 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, ASX_ROWS_MIN_WAVES) void k_row
         const float2 twa = tw_F(P, 2u * (uint32_t)k1 * tcol);
         const float2 twb = tw_F(P, 2u * (uint32_t)m1 * tcol);
         const float2 wk1 = tw_F(P, 2u * (uint32_t)k1), wm1 = tw_F(P, 2u * (uint32_t)m1); // w_M^k1, w_M^m1
-        {
+        bool fwd_done = false;
+        if constexpr (STATIC && ASX_ROWS_FED) {
+            if (fed) {
+                // No fill phase: the first row stage (legs q0 = M2/R0 elements apart) takes its inputs from HBM --
+                // 2*R0 eight-byte loads per thread, all in flight together -- times the four-step twiddle
+                // w_M^(row*(j + q0*t)) = w_M^(row*j) (one lookup per thread) * w_M^(row*q0*t) (R0 values per row,
+                // block-uniform, from LDS), and writes its outputs to LDS: one LDS write + read pass and one
+                // barrier less per block.
+                constexpr StageK K0 = S2::stage(0);
+                __shared__ float2 tw_leg[2][K0.R];
+                if ((int)threadIdx.x < 2 * K0.R) {
+                    const int which = (int)threadIdx.x >= K0.R;
+                    const int t = threadIdx.x - which * K0.R;
+                    tw_leg[which][t] = tw_F(P, 2u * (which ? (uint32_t)m1 : (uint32_t)k1) * (uint32_t)(K0.q * t));
+                }
+                __syncthreads(); // tw_leg (and tw_step for the store phase) visible
+                ASX_STAMP(1);
+                lds_fft_static_fed<S2, false, false>(A4, Lf, P.tw2, pre_f,
+                    [&](auto RC, auto &v, int g, int pos0, int q) __attribute__((always_inline)) {
+                        constexpr int R = decltype(RC)::value;
+                        const size_t ro = (size_t)(g ? pb : pa) * M2 + pos0;
+                        float2 x[R], y[R];
+                        static_for<0, R>([&](auto TT) __attribute__((always_inline)) {
+                            constexpr int t = decltype(TT)::value;
+                            x[t] = gxf[ro + t * q];
+                            y[t] = gyf[ro + t * q];
+                        });
+                        const float2 base = tw_F(P, 2u * (g ? (uint32_t)m1 : (uint32_t)k1) * (uint32_t)pos0);
+                        static_for<0, R>([&](auto TT) __attribute__((always_inline)) {
+                            constexpr int t = decltype(TT)::value;
+                            v[t] = mulw(Cx2{ v2f{ x[t].x, y[t].x }, v2f{ x[t].y, y[t].y } }, cmul(base, tw_leg[g][t]));
+                        });
+                    });
+                fwd_done = true;
+            }
+        }
+        if (!fwd_done) {
             __syncthreads();
             if (wide) {
                 static_for<0, ASX_ROW_WSTEPS>([&](auto I) __attribute__((always_inline)) {
@@ -501,12 +547,12 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, ASX_ROWS_MIN_WAVES) void k_row
                     }
                 });
             }
-        }
         __syncthreads();
         ASX_STAMP(1);
         if (!(ASX_ABL & 1)) {
         if constexpr (STATIC) lds_fft_static<S2, false, false>(A4, Lf, P.tw2, pre_f);
         else lds_fft<MAXR, false, false>(A4, PD.st2, Lf, P.tw2, pre_f);
+        }
         }
         ASX_STAMP(2);
 
