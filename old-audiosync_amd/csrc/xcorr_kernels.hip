@@ -1252,7 +1252,13 @@ __global__ __launch_bounds__(ASX_THREADS) void k_pearson_partial(const TIn *__re
     __shared__ double red[6][ASX_THREADS / 64];
     const size_t pair = blockIdx.y;
     const AsxSeg s = seg[pair];
-    const uint32_t chunk = (basis_len + ASX_PEARSON_BLOCKS - 1) / ASX_PEARSON_BLOCKS;
+    // gridDim.x <= ASX_PEARSON_BLOCKS partial blocks per pair (asx_pearson_blocks); the final kernel always
+    // merges ASX_PEARSON_BLOCKS entries, so block 0 marks the unused ones as empty (n = 0)
+    if (blockIdx.x == 0 && threadIdx.x >= gridDim.x && threadIdx.x < ASX_PEARSON_BLOCKS) {
+        double *z = psums + (pair * ASX_PEARSON_BLOCKS + threadIdx.x) * 6;
+        z[0] = z[1] = z[2] = z[3] = z[4] = z[5] = 0.0;
+    }
+    const uint32_t chunk = (basis_len + gridDim.x - 1) / gridDim.x;
     const uint64_t lo = (uint64_t)blockIdx.x * chunk;
     uint64_t hi = lo + chunk;
     if (hi > s.len) hi = s.len;
@@ -1626,11 +1632,23 @@ void asx_launch_refine_f64(const AsxDev &P, const double *src, const double *smp
     hipLaunchKernelGGL(k_refine_pick, dim3(npairs), dim3(ASX_THREADS), 0, s, P.self_dev, W, seg);
 }
 
+// Partial blocks per pair: at least 16 sweeps of the block over its chunk (a block that only makes two
+// pays more for its reduction than for its loads: 1024 pairs of N = 144 000 ran at 3.0 TB/s with 64
+// blocks per pair against 5.7 TB/s at N = 1 440 000), at most ASX_PEARSON_BLOCKS.
+static unsigned asx_pearson_blocks(uint32_t basis_len)
+{
+    const uint32_t per_block = 16u * 4u * ASX_THREADS;
+    uint32_t nb = (basis_len + per_block - 1) / per_block;
+    if (nb < 1) nb = 1;
+    if (nb > ASX_PEARSON_BLOCKS) nb = ASX_PEARSON_BLOCKS;
+    return nb;
+}
+
 void asx_launch_pearson_f32(const float *src, const float *smp, size_t src_pitch, size_t smp_pitch,
                             uint32_t basis_len, const AsxSeg *seg, double *psums, int64_t *lag,
                             double *coef, int32_t *ret, int npairs, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_pearson_partial<float>, dim3(ASX_PEARSON_BLOCKS, npairs), dim3(ASX_THREADS), 0, s,
+    hipLaunchKernelGGL(k_pearson_partial<float>, dim3(asx_pearson_blocks(basis_len), npairs), dim3(ASX_THREADS), 0, s,
                        src, smp, src_pitch, smp_pitch, basis_len, seg, psums);
     hipLaunchKernelGGL(k_pearson_final, dim3(npairs), dim3(64), 0, s, seg, psums, lag, coef, ret);
 }
@@ -1639,7 +1657,7 @@ void asx_launch_pearson_f64(const double *src, const double *smp, size_t src_pit
                             uint32_t basis_len, const AsxSeg *seg, double *psums, int64_t *lag,
                             double *coef, int32_t *ret, int npairs, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_pearson_partial<double>, dim3(ASX_PEARSON_BLOCKS, npairs), dim3(ASX_THREADS), 0, s,
+    hipLaunchKernelGGL(k_pearson_partial<double>, dim3(asx_pearson_blocks(basis_len), npairs), dim3(ASX_THREADS), 0, s,
                        src, smp, src_pitch, smp_pitch, basis_len, seg, psums);
     hipLaunchKernelGGL(k_pearson_final, dim3(npairs), dim3(64), 0, s, seg, psums, lag, coef, ret);
 }
