@@ -203,7 +203,7 @@ static int plan_init(asx_plan *p, size_t N, size_t max_batch, const char *split)
             dev_alloc(p, &ln.pk.pairmax, g) || dev_alloc(p, &ln.pk.cand_n, g) ||
             dev_alloc(p, &ln.pk.cand, g * cap) || dev_alloc(p, &ln.pk.refine_n, g) ||
             dev_alloc(p, &ln.pk.refine_idx, g * cap) || dev_alloc(p, &ln.pk.refine_val, g * cap) ||
-            dev_alloc(p, &ln.pk.overflows, 1) ||
+            dev_alloc(p, &ln.pk.overflows, 1) || dev_alloc(p, &ln.pk.ticket, 1) ||
             dev_alloc(p, &ln.seg, g) || dev_alloc(p, &ln.psums, g * ASX_PEARSON_BLOCKS * 6))
             return -1;
         HIP_TRY(hipMemset(ln.pk.overflows, 0, sizeof(unsigned long long)));

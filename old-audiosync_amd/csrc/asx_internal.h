@@ -107,6 +107,8 @@ struct AsxPeakWs {
     double *refine_val;    // [pairs][cap] exact r[idx]
     unsigned long long *overflows; // [1] pairs whose candidate list did not fit (float32 argmax kept), cumulative
     uint32_t cap;          // candidate capacity per pair
+    uint32_t *ticket;      // [1] task counter of a persistent k_rows launch (zeroed before the launch)
+    uint32_t ntasks_pairs; // pairs of the launch (filled in by the launcher)
 };
 
 void asx_launch_fwd_cols(const AsxDev &P, const float *src, const float *smp, float2 *zxa,

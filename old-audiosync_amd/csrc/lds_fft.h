@@ -314,6 +314,8 @@ struct LdsLayout {
     int elem_stride;           // in float4 slots
     int group_stride;
     int nthreads;              // block size (a literal in the kernels with a compile-time schedule)
+    int tid;                   // the thread's index in the block (threadIdx.x; a persistent kernel passes an opaque
+                               // copy per task so that per-thread table reads are not hoisted out of its task loop)
 };
 
 // Twiddle prefetch: the two table reads (W^1, W^4) a thread needs for its FIRST work item of a
@@ -367,7 +369,7 @@ __device__ __forceinline__ TwPre tw_prefetch_k(const StageK K, const LdsLayout &
     TwPre pre;
     pre.w1 = make_float2(1.f, 0.f);
     pre.w4 = make_float2(1.f, 0.f);
-    const int w = threadIdx.x;
+    const int w = L.tid;
     if (K.q == 1 || w >= L.ngroups * K.nbf) return pre;
     int bf;
     if (GFAST) bf = w >> L.log_ngroups;
@@ -428,7 +430,7 @@ __device__ __forceinline__ void lds_stage(float4 *lds, const StageK K, const Lds
 #ifndef ASX_EXP_NOCONF
     const int step = q * L.elem_stride;
 #endif
-    for (int w = threadIdx.x; w < total; w += L.nthreads) {
+    for (int w = L.tid; w < total; w += L.nthreads) {
         int g, bf;
         if (GFAST) {
             g = w & (L.ngroups - 1);
@@ -455,7 +457,7 @@ __device__ __forceinline__ void lds_stage(float4 *lds, const StageK K, const Lds
             Bfly<R, INV>::run(v);
         } else {
             float2 w1 = pre.w1, w4 = pre.w4;
-            if (w != (int)threadIdx.x) { // later work items of this thread: read the table now
+            if (w != L.tid) { // later work items of this thread: read the table now
                 const int tj = j * twmul;
                 w1 = tw[tj];
                 if constexpr (R > 4) w4 = tw[4 * tj];
@@ -560,7 +562,7 @@ __device__ __forceinline__ TwPre tw_prefetch_wavepair(const LdsLayout &L, const 
 {
     using WP = WavePair<S, I>;
     TwPre pre{ make_float2(1.f, 0.f), make_float2(1.f, 0.f) };
-    const int lane = threadIdx.x & 63;
+    const int lane = L.tid & 63;
     if (WP::K0.q == 1 || lane >= WP::UPW * WP::Q) return pre;
     const int j = lane % WP::Q;
     const int tj = j * WP::K0.twmul;
@@ -575,7 +577,7 @@ __device__ __forceinline__ void lds_stage_wavepair(float4 *lds, const LdsLayout 
     using WP = WavePair<S, I>;
     constexpr int R = WP::R, Q = WP::Q, UPW = WP::UPW;
     constexpr StageK K0 = WP::K0, K1 = WP::K1;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = L.nthreads >> 6;
+    const int lane = L.tid & 63, wave = L.tid >> 6, nwaves = L.nthreads >> 6;
     const int nunits = L.ngroups * WP::NSUB;
     const int ul = lane / Q, j = lane - ul * Q;   // unit within the wave, butterfly within the unit
     for (int u0 = wave * UPW; u0 < nunits; u0 += nwaves * UPW) { // wave-uniform trip count
@@ -736,7 +738,7 @@ __device__ __forceinline__ void lds_last_stage(float4 *lds, const AsxStages &st,
 {
     if (st.nstages < 1) {
         // a one-point transform (M1 = 1): the tile itself is the result
-        for (int w = threadIdx.x; w < L.ngroups * st.n; w += L.nthreads) {
+        for (int w = L.tid; w < L.ngroups * st.n; w += L.nthreads) {
             int g, e;
             if (GFAST) { g = w & (L.ngroups - 1); e = w >> L.log_ngroups; }
             else { g = w / st.n; e = w - g * st.n; }

@@ -144,6 +144,7 @@ __device__ __forceinline__ LdsLayout col_layout(int T, int logT, int nthreads)
     L.elem_stride = T >> 1;
     L.group_stride = 1;
     L.nthreads = nthreads;
+    L.tid = threadIdx.x;
     return L;
 }
 constexpr int asx_ilog2(int v) { return v <= 1 ? 0 : 1 + asx_ilog2(v >> 1); }
@@ -380,9 +381,18 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, ASX_ROWS_MIN_WAVES) void k_row
     float4 *A4 = reinterpret_cast<float4 *>(asx_lds), *B4 = A4 + M2;
     __shared__ float2 tw_step[2][ASX_ROW_STEPS];
 
-    // one task per block (grid = ntasks)
-    const int task = blockIdx.x;
-    {
+#ifndef ASX_ROWS_PERSIST
+#define ASX_ROWS_PERSIST 0 // 1: 4 blocks per CU that pull tasks from a ticket counter instead of one block per task
+#endif
+    // one task per block (grid = ntasks), or (ASX_ROWS_PERSIST) resident blocks that pull tasks: the first
+    // task of a block is its index, every further one a ticket taken one task ahead (the atomic's latency
+    // hides behind the task in progress)
+    __shared__ int s_next[2];
+    int task = blockIdx.x, iter = 0;
+    const int ntasks = ASX_ROWS_PERSIST ? nrows * (int)W.ntasks_pairs : (int)gridDim.x;
+    while (task < ntasks) {
+        int next_ticket = 0;
+        if (ASX_ROWS_PERSIST && threadIdx.x == 0) next_ticket = (int)gridDim.x + (int)atomicAdd(W.ticket, 1u);
         const int pair = task / nrows;
         const int4 rt = row_tasks[task - pair * nrows];
         int pa = rt.x, pb = rt.y;
@@ -406,10 +416,15 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, ASX_ROWS_MIN_WAVES) void k_row
         }
         LdsLayout Lf;
         Lf.ngroups = self ? 1 : 2; Lf.log_ngroups = 0;
-        Lf.elem_stride = 1; Lf.group_stride = M2; Lf.nthreads = nthreads;
+        // Per-thread table reads (stage twiddles, four-step twiddles) depend on the thread index only; in the
+        // persistent form the compiler would hoist them all out of the task loop (128 VGPRs + spills), so the
+        // loop body sees an opaque copy of the index.
+        int tid = threadIdx.x;
+        if (ASX_ROWS_PERSIST) asm volatile("" : "+v"(tid));
+        Lf.elem_stride = 1; Lf.group_stride = M2; Lf.nthreads = nthreads; Lf.tid = tid;
         LdsLayout Li;
         Li.ngroups = 1; Li.log_ngroups = 0;
-        Li.elem_stride = 1; Li.group_stride = 0; Li.nthreads = nthreads;
+        Li.elem_stride = 1; Li.group_stride = 0; Li.nthreads = nthreads; Li.tid = tid;
         // Every row load of the thread is issued first; the twiddle lookups below overlap them.
         // Rows of even length move as 16 bytes per lane (two complex values): a block's burst of
         // 8-byte loads takes 2-3x as long to come back (tools/micro/rowload_latency.hip: 21 k cycles
@@ -436,7 +451,7 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, ASX_ROWS_MIN_WAVES) void k_row
 #endif
             if (wide) {
                 static_for<0, ASX_ROW_WSTEPS>([&](auto I) __attribute__((always_inline)) {
-                    const int q = threadIdx.x + decltype(I)::value * nthreads;
+                    const int q = tid + decltype(I)::value * nthreads;
                     LW.xa[I] = LW.ya[I] = LW.xb[I] = LW.yb[I] = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (q < half) {
                         LW.xa[I] = asx_ld16(gx + (size_t)pa * M2 + 2 * q, ASX_NT & 1);
@@ -449,7 +464,7 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, ASX_ROWS_MIN_WAVES) void k_row
                 });
             } else {
                 static_for<0, ASX_ROW_STEPS>([&](auto I) __attribute__((always_inline)) {
-                    const int j2 = threadIdx.x + decltype(I)::value * nthreads;
+                    const int j2 = tid + decltype(I)::value * nthreads;
                     L.xa[I] = L.ya[I] = L.xb[I] = L.yb[I] = make_float2(0.f, 0.f);
                     if (j2 < M2) {
                         L.xa[I] = gx[(size_t)pa * M2 + j2];
@@ -471,13 +486,13 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, ASX_ROWS_MIN_WAVES) void k_row
         // lookup per thread), w_M^(k1*c*nthreads*i) (a handful per block) and w_M^(k1*h) (block-uniform).
         const int cw = wide ? 2 : 1;
         const int nsteps = wide ? (half + nthreads - 1) / nthreads : (M2 + nthreads - 1) / nthreads; // <= ASX_ROW_STEPS (launcher)
-        if ((int)threadIdx.x < 2 * nsteps) {
-            const int which = (int)threadIdx.x >= nsteps;
-            const int i = threadIdx.x - which * nsteps;
+        if (tid < 2 * nsteps) {
+            const int which = tid >= nsteps;
+            const int i = tid - which * nsteps;
             const uint32_t row = which ? (uint32_t)m1 : (uint32_t)k1;
             tw_step[which][i] = tw_F(P, 2u * row * (uint32_t)(cw * i * nthreads));
         }
-        const uint32_t tcol = (uint32_t)cw * threadIdx.x < (unsigned)M2 ? (uint32_t)cw * threadIdx.x : 0u;
+        const uint32_t tcol = (uint32_t)cw * tid < (unsigned)M2 ? (uint32_t)cw * tid : 0u;
         const float2 twa = tw_F(P, 2u * (uint32_t)k1 * tcol);
         const float2 twb = tw_F(P, 2u * (uint32_t)m1 * tcol);
         const float2 wk1 = tw_F(P, 2u * (uint32_t)k1), wm1 = tw_F(P, 2u * (uint32_t)m1); // w_M^k1, w_M^m1
@@ -491,9 +506,9 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, ASX_ROWS_MIN_WAVES) void k_row
                 // barrier less per block.
                 constexpr StageK K0 = S2::stage(0);
                 __shared__ float2 tw_leg[2][K0.R];
-                if ((int)threadIdx.x < 2 * K0.R) {
-                    const int which = (int)threadIdx.x >= K0.R;
-                    const int t = threadIdx.x - which * K0.R;
+                if (tid < 2 * K0.R) {
+                    const int which = tid >= K0.R;
+                    const int t = tid - which * K0.R;
                     tw_leg[which][t] = tw_F(P, 2u * (which ? (uint32_t)m1 : (uint32_t)k1) * (uint32_t)(K0.q * t));
                 }
                 __syncthreads(); // tw_leg (and tw_step for the store phase) visible
@@ -522,7 +537,7 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, ASX_ROWS_MIN_WAVES) void k_row
             if (wide) {
                 static_for<0, ASX_ROW_WSTEPS>([&](auto I) __attribute__((always_inline)) {
                     constexpr int i = decltype(I)::value;
-                    const int q = threadIdx.x + i * nthreads;
+                    const int q = tid + i * nthreads;
                     if (q < half) {
                         const float2 wa0 = cmul(twa, tw_step[0][i]), wa1 = cmul(wa0, wk1);
                         lds_put(A4 + 2 * q, mulw(Cx2{ v2f{ LW.xa[I].x, LW.ya[I].x }, v2f{ LW.xa[I].y, LW.ya[I].y } }, wa0));
@@ -537,7 +552,7 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, ASX_ROWS_MIN_WAVES) void k_row
             } else {
                 static_for<0, ASX_ROW_STEPS>([&](auto I) __attribute__((always_inline)) {
                     constexpr int i = decltype(I)::value;
-                    const int j2 = threadIdx.x + i * nthreads;
+                    const int j2 = tid + i * nthreads;
                     if (j2 < M2) {
                         lds_put(A4 + j2, mulw(Cx2{ v2f{ L.xa[I].x, L.ya[I].x }, v2f{ L.xa[I].y, L.ya[I].y } },
                                               cmul(twa, tw_step[0][i])));
@@ -576,7 +591,7 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, ASX_ROWS_MIN_WAVES) void k_row
             int sl[ASX_ROW_WSTEPS];
             static_for<0, ASX_ROW_WSTEPS>([&](auto I) __attribute__((always_inline)) {
                 constexpr int i = decltype(I)::value;
-                const int sx = threadIdx.x + i * nthreads;
+                const int sx = tid + i * nthreads;
                 sl[i] = sx < npairs2 ? sx : 0; // clamped: the loads are unconditional
                 w2a[i] = P.tw2s[sl[i]];
                 w2b[i] = P.tw2s[M2 - 1 - sl[i]];
@@ -593,7 +608,7 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, ASX_ROWS_MIN_WAVES) void k_row
             });
             static_for<0, ASX_ROW_WSTEPS>([&](auto I) __attribute__((always_inline)) {
                 constexpr int i = decltype(I)::value;
-                const int sx = threadIdx.x + i * nthreads;
+                const int sx = tid + i * nthreads;
                 float2 gk0, gm0, gk1, gm1;
                 combine_pair(za[i], zb[i], cmul(wA, w2a[i]), gk0, gm0); // bin(s) of k1 with bin(s') of m1
                 combine_pair(zc[i], zd[i], cmul(wA, w2b[i]), gk1, gm1); // bin(s') of k1 with bin(s) of m1
@@ -615,7 +630,7 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, ASX_ROWS_MIN_WAVES) void k_row
         int sa[ASX_ROW_STEPS], sb[ASX_ROW_STEPS]; // -1: nothing to write
         static_for<0, ASX_ROW_STEPS>([&](auto I) __attribute__((always_inline)) {
             constexpr int i = decltype(I)::value;
-            const int k2 = threadIdx.x + i * nthreads;
+            const int k2 = tid + i * nthreads;
             sa[i] = -1; sb[i] = -1;
             gk[i] = make_float2(0.f, 0.f); gm[i] = make_float2(0.f, 0.f);
             if (ASX_ABL & 2) {
@@ -676,14 +691,14 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, ASX_ROWS_MIN_WAVES) void k_row
             Cx2 g0[ASX_ROW_WSTEPS], g1[ASX_ROW_WSTEPS];
             static_for<0, ASX_ROW_WSTEPS>([&](auto I) __attribute__((always_inline)) {
                 constexpr int i = decltype(I)::value;
-                const int q = threadIdx.x + i * nthreads;
+                const int q = tid + i * nthreads;
                 const int qq = q < half ? q : 0;
                 g0[i] = lds_get(A4 + 2 * qq);
                 g1[i] = lds_get(A4 + 2 * qq + 1);
             });
             static_for<0, ASX_ROW_WSTEPS>([&](auto I) __attribute__((always_inline)) {
                 constexpr int i = decltype(I)::value;
-                const int q = threadIdx.x + i * nthreads;
+                const int q = tid + i * nthreads;
                 if (q < half) {
                     const float2 wa0 = cmul(twa, tw_step[0][i]), wb0 = cmul(twb, tw_step[1][i]);
                     const float2 wa1 = cmul(wa0, wk1), wb1 = cmul(wb0, wm1);
@@ -698,12 +713,12 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, ASX_ROWS_MIN_WAVES) void k_row
             Cx2 gout[ASX_ROW_STEPS];
             static_for<0, ASX_ROW_STEPS>([&](auto I) __attribute__((always_inline)) {
                 constexpr int i = decltype(I)::value;
-                const int j2 = threadIdx.x + i * nthreads;
+                const int j2 = tid + i * nthreads;
                 gout[i] = lds_get(A4 + (j2 < M2 ? j2 : 0));
             });
             static_for<0, ASX_ROW_STEPS>([&](auto I) __attribute__((always_inline)) {
                 constexpr int i = decltype(I)::value;
-                const int j2 = threadIdx.x + i * nthreads;
+                const int j2 = tid + i * nthreads;
                 if (j2 < M2) {
                     const float2 wa = cmul(twa, tw_step[0][i]), wb = cmul(twb, tw_step[1][i]);
                     const Cx2 g = mul2c(gout[i], Cx2{ v2f{ wa.x, wb.x }, v2f{ wa.y, wb.y } });
@@ -713,6 +728,11 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, ASX_ROWS_MIN_WAVES) void k_row
             });
         }
         ASX_STAMP(5);
+        if (!ASX_ROWS_PERSIST) break;
+        if (threadIdx.x == 0) s_next[iter & 1] = next_ticket;
+        __syncthreads(); // the ticket is visible, and nobody still reads this task's rows from LDS
+        task = s_next[iter & 1];
+        iter++;
     }
 }
 
@@ -1497,7 +1517,25 @@ void asx_launch_fwd_cols_generic(const AsxDev &P, const float *src, const float 
 
 #define ASX_ROWS_LAUNCH(...) \
     do { allow_big_lds((const void *)k_rows<__VA_ARGS__>, lds); \
-         hipLaunchKernelGGL((k_rows<__VA_ARGS__>), dim3(ntasks), dim3(P.threads_rows), lds, s, P.self_dev, zxa, zya, ga, P.row_tasks, P.M1, P.M2, P.M, W); } while (0)
+         AsxPeakWs Wk = W; Wk.ntasks_pairs = (uint32_t)npairs; \
+         int grid = ntasks; \
+         if (ASX_ROWS_PERSIST) { \
+             int per_cu = 0; \
+             (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_rows<__VA_ARGS__>, P.threads_rows, lds); \
+             grid = std::min(ntasks, std::max(1, per_cu) * asx_cu_count()); \
+             (void)hipMemsetAsync(W.ticket, 0, sizeof(uint32_t), s); \
+         } \
+         hipLaunchKernelGGL((k_rows<__VA_ARGS__>), dim3(grid), dim3(P.threads_rows), lds, s, P.self_dev, zxa, zya, ga, P.row_tasks, P.M1, P.M2, P.M, Wk); } while (0)
+static int asx_cu_count()
+{
+    static int n = 0;
+    if (n > 0) return n;
+    int dev = 0, c = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c < 1) return 256;
+    n = c;
+    return n;
+}
 static size_t rows_lds_request(const AsxDev &P)
 {
     size_t lds = lds_bytes_rows(P);
