@@ -484,8 +484,8 @@ def run_rank(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--sample-len", type=int, default=1440000)
     ap.add_argument("--batch", type=int, default=0, help="pairs per GPU per step (0 = auto)")
     ap.add_argument("--noise-shift", type=int, default=1)
