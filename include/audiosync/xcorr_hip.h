@@ -87,6 +87,9 @@ void asx_plan_destroy(asx_plan *plan);
  * Both getters synchronise the plan's streams. */
 int asx_plan_peak_overflows(asx_plan *plan, uint64_t *count);
 int asx_plan_peak_repairs(asx_plan *plan, uint64_t *count);
+/* on != 0: asx_xcorr_batch_f32_dev also takes the second look (it then synchronises with the host once
+ * per launch group, which costs about 1 % of the throughput); default off. */
+int asx_plan_set_exact(asx_plan *plan, int on);
 size_t asx_plan_peak_capacity(const asx_plan *plan);
 
 /* Introspection (used by tests, bench and DESIGN.md's numbers). */

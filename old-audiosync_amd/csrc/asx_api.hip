@@ -117,6 +117,7 @@ struct asx_plan {
     } big;
     std::vector<uint32_t> h_cand_n;
     unsigned long long repaired = 0;   // pairs that took the second look
+    bool exact_async = false;          // asx_plan_set_exact: the device-resident batch also takes the second look
     // staging for the host-pointer entry points (lazy)
     float *st_src = nullptr, *st_smp = nullptr;
     int64_t *st_lag = nullptr;
@@ -385,6 +386,14 @@ extern "C" int asx_plan_peak_overflows(asx_plan *p, uint64_t *count)
     return 0;
 }
 
+extern "C" int asx_plan_set_exact(asx_plan *p, int on)
+{
+    if (!p) return fail("asx_plan_set_exact: null argument");
+    std::lock_guard<std::mutex> guard(p->lock);
+    p->exact_async = on != 0;
+    return 0;
+}
+
 extern "C" int asx_plan_peak_repairs(asx_plan *p, uint64_t *count)
 {
     if (!p || !count) return fail("asx_plan_peak_repairs: null argument");
@@ -584,6 +593,12 @@ extern "C" int asx_xcorr_batch_f32_dev(asx_plan *p, const float *d_source, const
         if (run_group<float>(p, d_source + done * 2 * N, d_sample + done * N, d_source + done * 2 * N,
                              d_sample + done * N, g, d_lag ? d_lag + done : nullptr, d_coef + done,
                              d_ret ? d_ret + done : nullptr, nullptr, ls, gi, lane))
+            return -1;
+        // asx_plan_set_exact: look at the group's counters (one host synchronisation per group) and take the
+        // second look at pairs whose near-tie list overflowed, before the next group reuses the workspaces
+        if (p->exact_async &&
+            repair_overflows<float>(p, lane, g, d_source + done * 2 * N, d_sample + done * N, d_lag ? d_lag + done : nullptr,
+                                    d_coef + done, d_ret ? d_ret + done : nullptr, ls))
             return -1;
     }
     if (overlap) {

@@ -52,7 +52,8 @@
 #ifndef ASX_ABL
 #define ASX_ABL 0
 #endif
-// Experiment: ASX_NT & 1 non-temporal row loads in k_rows, & 2 non-temporal row stores, & 4 non-temporal loads in the Pearson pass
+// ASX_NT bits (non-temporal accesses): 1 row loads of k_rows, 2 its row stores, 4 loads of the Pearson pass,
+// 8 tile stores of k_fwd_cols, 16 tile loads of k_inv_cols
 #ifndef ASX_NT
 #define ASX_NT 4 // Pearson reads its inputs once: non-temporal loads, 0.213 -> 0.201 ms; the row kernel got slower with them
 #endif
@@ -305,7 +306,7 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_fwd_cols(const AsxDe
         const int j2 = c0 + 2 * cg;
         if (full) {
             const float4 v = lds4[e];
-            *reinterpret_cast<float4 *>(out + (size_t)p1 * M2 + j2) = v;
+            asx_st16(out + (size_t)p1 * M2 + j2, v, ASX_NT & 8);
         } else if (j2 < M2) {
             const float4 v = lds4[e];
             float2 *o = out + (size_t)p1 * M2 + j2;
@@ -886,7 +887,7 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_inv_cols(const AsxDe
                     const float2 *col = in + (size_t)pos0 * M2 + c0 + 2 * g;
                     static_for<0, decltype(RC)::value>([&](auto TT) __attribute__((always_inline)) {
                         constexpr int t = decltype(TT)::value;
-                        const float4 x = *reinterpret_cast<const float4 *>(col + (size_t)(t * q) * M2);
+                        const float4 x = asx_ld16(col + (size_t)(t * q) * M2, ASX_NT & 16);
                         v[t] = Cx2{ v2f{ x.x, x.z }, v2f{ x.y, x.w } };
                     });
                 });

@@ -23,7 +23,7 @@ ABI_SYMBOLS = [
     "asx_xcorr_debug_r_dev", "asx_pearson_f64", "asx_results_to_ms_dev", "asx_stream_create", "asx_stream_destroy",
     "asx_stream_append_f64", "asx_stream_lengths", "asx_stream_reset", "asx_stream_xcorr", "asx_synth_pairs_dev", "asx_plan_set_profiling",
     "asx_plan_last_timings_ms", "asx_device_malloc", "asx_device_free", "asx_memcpy_h2d",
-    "asx_memcpy_d2h", "asx_stream_sync", "asx_plan_peak_overflows", "asx_plan_peak_repairs", "asx_plan_peak_capacity",
+    "asx_memcpy_d2h", "asx_stream_sync", "asx_plan_peak_overflows", "asx_plan_peak_repairs", "asx_plan_set_exact", "asx_plan_peak_capacity",
     "asx_current_device", "asx_plan_timings_ms", "asx_xcorr_batch_multi",
 ]
 
@@ -68,6 +68,8 @@ def lib():
     L.asx_plan_destroy.argtypes = [vp]
     L.asx_plan_peak_overflows.restype = ctypes.c_int
     L.asx_plan_peak_overflows.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
+    L.asx_plan_set_exact.restype = ctypes.c_int
+    L.asx_plan_set_exact.argtypes = [vp, ctypes.c_int]
     L.asx_plan_peak_repairs.restype = ctypes.c_int
     L.asx_plan_peak_repairs.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
     for name in ("asx_plan_sample_len", "asx_plan_fft_len", "asx_plan_group", "asx_plan_workspace_bytes",
@@ -322,6 +324,11 @@ class Plan:
         if lib().asx_plan_peak_overflows(self._h, ctypes.byref(c)) != 0:
             raise AsxError(_err())
         return c.value
+
+    def set_exact(self, on=True):
+        """the asynchronous device batch also re-examines overflowing pairs (one host sync per launch group)"""
+        if lib().asx_plan_set_exact(self._h, 1 if on else 0) != 0:
+            raise AsxError(_err())
 
     def peak_repairs(self):
         """overflowing pairs the synchronous entry points looked at again with lists for all 2N lags"""

@@ -159,6 +159,12 @@ def test_overflow_is_counted_and_looked_at_again(mod):
         plan.xcorr_batch_dev(d_src.data_ptr(), d_smp.data_ptr(), 2, d_lag.data_ptr(), d_coef.data_ptr(), d_ret.data_ptr())
         assert plan.peak_overflows() == 4 and plan.peak_repairs() == 2
         assert int(d_lag[1]) % 8 == 0 and int(d_ret[0]) == -1
+        # ... unless the plan is told to (asx_plan_set_exact): then it synchronises per group and looks again
+        plan.set_exact(True)
+        d_lag.fill_(-99)
+        plan.xcorr_batch_dev(d_src.data_ptr(), d_smp.data_ptr(), 2, d_lag.data_ptr(), d_coef.data_ptr(), d_ret.data_ptr())
+        assert plan.peak_overflows() == 6 and plan.peak_repairs() == 4
+        assert int(d_lag[1]) == 0 and int(d_lag[0]) == 0 and int(d_ret[0]) == -1 and float(d_coef[1]) == 1.0
     assert int(ret[0]) == -1 and int(lag[0]) == 0          # like the reference: index 0, NaN coefficient
     # 12 000 exactly tied peaks (every 8th lag): the exact values tie, the smallest lag wins as in a sequential scan
     assert int(ret[1]) == 0 and int(lag[1]) == 0 and coef[1] == 1.0
