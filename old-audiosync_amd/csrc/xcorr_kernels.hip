@@ -925,7 +925,7 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_inv_cols(const AsxDe
     // every inverse stage but the last: the last one's outputs are consumed from registers below
     // (r reaches neither HBM nor LDS; LDS keeps that stage's input, so the stage can be run again)
     if constexpr (STATIC) pre_last = lds_fft_static_head<S1, true, true>(lds4, Lc, P.tw1, pre);
-    else pre_last = lds_fft_head<MAXR, true, true>(lds4, PD.st1, Lc, P.tw1, pre);
+    else lds_fft<MAXR, true, true>(lds4, PD.st1, Lc, P.tw1, pre); // run-time schedule: the whole transform, r into LDS
     }
     ASX_STAMP_AT(2, stamp_block, 2);
 
@@ -935,10 +935,105 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_inv_cols(const AsxDe
     // candidates (k_finalize filters them against the final maximum).
     const asx_peak_t run0 = W.pairmax[pair];
     const float b2 = W.bound2[pair];
+    if constexpr (!STATIC) {
+        // Run-time schedules (lengths outside the reference's six): r lies in LDS and is scanned there.  The
+        // scan from the last stage's registers below, instantiated inside the switch over eleven radix bodies,
+        // pushed these kernels into scratch (k_inv_cols 0.77 ms against 0.43 ms for the compiled-in schedule).
+        const bool fastg = even && (c0 + T <= M2) && (P.nout == P.F) && (tile != 0) && (r_out == nullptr);
+        auto examine_slot = [&](int e, float4 g, float thr) {
+            const int cg = e & (H - 1), j1 = e >> logH;
+            const int j2 = c0 + 2 * cg;
+            if (j2 >= M2) return;
+            const uint32_t i0 = 2u * ((uint32_t)j1 * (uint32_t)M2 + (uint32_t)j2);
+            const float val[4] = { g.x, g.y, g.z, g.w }; // slot = {re0, im0, re1, im1}: four consecutive lags
+#pragma unroll
+            for (int h = 0; h < 4; h++) {
+                const uint32_t idx = i0 + h;
+                if (idx < P.nout && j2 + (h >> 1) < M2) {
+                    const float key = peak_key_of(val[h], idx);
+                    if (key >= thr) cand_append(W, pair, idx, key);
+                }
+            }
+        };
+        if (fastg) {
+            // pass 1: per thread the largest and second largest slot maximum; a thread meets its slots in
+            // increasing lag order, so a strict '>' keeps the earliest of equal maxima
+            float best_m = -INFINITY, second_m = -INFINITY;
+            int best_e = threadIdx.x;
+            for (int e = threadIdx.x; e < nelem4; e += nthreads) {
+                const float4 g = lds4[e];
+                const float m = fmaxf(fmaxf(fabsf(g.x), fabsf(g.y)), fmaxf(fabsf(g.z), fabsf(g.w))); // NaNs drop out
+                if (m > best_m) { second_m = best_m; best_m = m; best_e = e; }
+                else if (m > second_m) second_m = m;
+            }
+            const float4 gb = lds4[best_e];
+            uint32_t my_idx;
+            {
+                const int cg = best_e & (H - 1), j1 = best_e >> logH;
+                const uint32_t i0 = 2u * ((uint32_t)j1 * (uint32_t)M2 + (uint32_t)(c0 + 2 * cg));
+                const uint32_t h = fabsf(gb.x) == best_m ? 0u : fabsf(gb.y) == best_m ? 1u : fabsf(gb.z) == best_m ? 2u : 3u;
+                my_idx = i0 + h;
+            }
+            const float wmax = wave_max_nonneg(fmaxf(best_m, 0.f));
+            unsigned long long holders = __ballot(best_m == wmax);
+            uint32_t widx = 0xFFFFFFFFu;
+            while (holders) {
+                const int l = __ffsll((long long)holders) - 1;
+                const uint32_t li = (uint32_t)__builtin_amdgcn_readlane((int)my_idx, l);
+                widx = li < widx ? li : widx;
+                holders &= holders - 1;
+            }
+            if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = widx == 0xFFFFFFFFu ? 0 : peak_pack_key(wmax, widx);
+            __syncthreads();
+            asx_peak_t tb = red[0];
+            for (int w = 1; w < (int)((nthreads + 63) >> 6); w++) tb = peak_max(tb, red[w]);
+            if (threadIdx.x == 0) atomicMax(&W.pairmax[pair], tb);
+            const float thr = near_max_threshold(peak_key(peak_max(tb, run0)), b2);
+            if (best_m >= thr) {
+                if (second_m >= thr) {
+                    for (int e = threadIdx.x; e < nelem4; e += nthreads) {
+                        const float4 g = lds4[e];
+                        const float m = fmaxf(fmaxf(fabsf(g.x), fabsf(g.y)), fmaxf(fabsf(g.z), fabsf(g.w)));
+                        if (m >= thr) examine_slot(e, g, thr);
+                    }
+                } else {
+                    examine_slot(best_e, gb, thr);
+                }
+            }
+        } else {
+            float best_key = -INFINITY;
+            uint32_t best_idx = 0xFFFFFFFFu;
+            for (int e = threadIdx.x; e < nelem4; e += nthreads) {
+                const int cg = e & (H - 1), j1 = e >> logH;
+                const int j2 = c0 + 2 * cg;
+                if (j2 < M2) {
+                    const uint32_t i0 = 2u * ((uint32_t)j1 * (uint32_t)M2 + (uint32_t)j2);
+                    const float4 g = lds4[e];
+                    const float val[4] = { g.x, g.y, g.z, g.w };
+#pragma unroll
+                    for (int h = 0; h < 4; h++) {
+                        const uint32_t idx = i0 + h;
+                        if (idx < P.nout && j2 + (h >> 1) < M2) {
+                            const float key = peak_key_of(val[h], idx);
+                            if (key > best_key || (key == best_key && idx < best_idx) || best_idx == 0xFFFFFFFFu) { best_key = key; best_idx = idx; }
+                            if (r_out) r_out[pair * (size_t)P.nout + idx] = val[h];
+                        }
+                    }
+                }
+            }
+            asx_peak_t best = best_idx == 0xFFFFFFFFu ? 0 : peak_pack_key(best_key, best_idx);
+            best = block_peak_max(best, red);
+            if (threadIdx.x == 0) { atomicMax(&W.pairmax[pair], best); red[0] = best; }
+            __syncthreads();
+            const float thr = near_max_threshold(peak_key(peak_max(red[0], run0)), b2);
+            for (int e = threadIdx.x; e < nelem4; e += nthreads) examine_slot(e, lds4[e], thr);
+        }
+        ASX_STAMP_AT(2, stamp_block, 3);
+    } else {
     auto last_stage = [&](auto &&sink) __attribute__((always_inline)) {
-        if constexpr (STATIC) lds_last_stage_static<S1, true, true>(lds4, Lc, P.tw1, pre_last, sink);
-        else lds_last_stage<MAXR, true, true>(lds4, PD.st1, Lc, P.tw1, pre_last, sink);
+        lds_last_stage_static<S1, true, true>(lds4, Lc, P.tw1, pre_last, sink);
     };
+
     // Output T of a butterfly is row j1 = pos0 + T*q of column pair g: four consecutive lags
     // {re0, im0, re1, im1} from i0 = 2*(j1*M2 + c0 + 2g).
     // Peak search (src/cross_correlation.c:52-67): largest key, smallest lag among equal keys.
@@ -1049,6 +1144,7 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_inv_cols(const AsxDe
     }
     if (again) examine_again(thr_again);
     ASX_STAMP_AT(2, stamp_block, 3);
+    } // compiled-in schedules
 }
 
 #if ASX_HAS_PART(64)
