@@ -14,15 +14,16 @@ __global__ __launch_bounds__(256) void k_copy(const float4 *in, float4 *out, siz
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) out[i] = in[i];
 }
 // tile pattern: matrix [rows][row_f4] of float4; a block moves a tile of 4 float4 (64 B) x all rows of one matrix
-__global__ __launch_bounds__(512) void k_tiles(const float4 *in, float4 *out, int rows, int row_f4, int tiles_per_mat)
+// pitch_f4 >= row_f4: row pitch in float4 (padded pitches: does a row stride that is not 9600 bytes move faster?)
+__global__ __launch_bounds__(512) void k_tiles(const float4 *in, float4 *out, int rows, int pitch_f4, int tiles_per_mat, int ntiles)
 {
     const int mat = blockIdx.x / tiles_per_mat, b = blockIdx.x % tiles_per_mat;
     const int tile = (b & ~15) + 2 * (b & 7) + ((b >> 3) & 1); // the XCD-aware pairing of xcorr_kernels.hip
-    if (tile >= tiles_per_mat) return;
-    const size_t base = (size_t)mat * rows * row_f4 + (size_t)tile * 4;
+    if (tile >= ntiles) return;
+    const size_t base = (size_t)mat * rows * pitch_f4 + (size_t)tile * 4;
     for (int e = threadIdx.x; e < rows * 4; e += 512) {
         const int r = e >> 2, c = e & 3;
-        out[base + (size_t)r * row_f4 + c] = in[base + (size_t)r * row_f4 + c];
+        out[base + (size_t)r * pitch_f4 + c] = in[base + (size_t)r * pitch_f4 + c];
     }
 }
 template <typename F> static float ms_of(F f)
@@ -46,10 +47,12 @@ int main()
     }
     // 1200 x 1200 complex per matrix = 1200 rows x 600 float4; 150 tiles (padded to 160 blocks); as many matrices as fit in 2 GiB
     const int rows = 1200, row_f4 = 600, tiles = 150, tpm = 160;
-    const int mats = (int)(bytes / ((size_t)rows * row_f4 * 16));
-    float t = ms_of([&] { hipLaunchKernelGGL(k_tiles, dim3(mats * tpm), dim3(512), 0, 0, a, b, rows, row_f4, tpm); });
-    (void)tiles;
-    printf("tiles %6d blocks: %.3f ms  %.2f TB/s (read+write, 64-byte pieces per row, paired tiles on one XCD)\n", mats * tpm, t,
-           2.0 * mats * (double)rows * row_f4 * 16 * 150 / 150 / t / 1e9);
+    for (int pad : { 0, 4, 8, 16, 24, 40, 72, 136 }) { // extra float4 per row: pitch 9600 B + 64, 128, 256, ... bytes
+        const int pitch = row_f4 + pad;
+        const int mats = (int)(bytes / ((size_t)rows * pitch * 16));
+        float t = ms_of([&] { hipLaunchKernelGGL(k_tiles, dim3(mats * tpm), dim3(512), 0, 0, a, b, rows, pitch, tpm, tiles); });
+        printf("tiles pitch %5d B, %6d blocks: %.3f ms  %.2f TB/s (read+write, 64-byte pieces per row, paired tiles on one XCD)\n",
+               pitch * 16, mats * tpm, t, 2.0 * mats * (double)rows * row_f4 * 16 / t / 1e9);
+    }
     return 0;
 }
