@@ -67,7 +67,7 @@ def test_every_kernel_is_built_for_gfx950_and_none_spills_in_the_production_vari
 def test_k_rows_headline_kernel_keeps_four_blocks_per_cu(kernels):
     names = {demangled(k): v for k, v in kernels.items()}
     (n, r), = [(n, r) for n, r in names.items() if n.startswith("void k_rows<12, Sched<1200, 12, 10, 10>, 256>")]
-    assert r["vgpr_count"] <= 104, r                       # 4 waves per SIMD with room; 96 today
+    assert r["vgpr_count"] <= 128, r                       # four waves per SIMD (125 with the iterative ILP scheduler)
     lds_dynamic = 4 * 1200 * 8                             # four rows of M2 = 1200 complex values
     assert 4 * (lds_dynamic + r["group_segment_fixed_size"]) <= 160 * 1024, r
 

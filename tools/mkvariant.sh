@@ -10,7 +10,9 @@ F="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-finite-math-only -fno-slp-vec
 objs="$P/build/asx_api.o $P/build/plan_math.o"
 for p in 1 2 4 8 16 32 64; do
   if [[ " $parts " == *" $p "* ]]; then
-    /opt/rocm/bin/hipcc $F $flags -DASX_PART=$p -c -o /tmp/asx_var/$name/k$p.o $P/csrc/xcorr_kernels.hip &
+    kf=""; case $p in 1|4|16) kf="-mllvm -amdgpu-sched-strategy=iterative-ilp";; esac   # as in the Makefile (KFLAGS_STATIC)
+    [ -n "$ASX_NO_KFLAGS" ] && kf=""
+    /opt/rocm/bin/hipcc $F $kf $flags -DASX_PART=$p -c -o /tmp/asx_var/$name/k$p.o $P/csrc/xcorr_kernels.hip &
     objs="$objs /tmp/asx_var/$name/k$p.o"
   else
     objs="$objs $P/build/kernels_$p.o"
