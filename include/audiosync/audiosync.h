@@ -102,6 +102,14 @@ extern int audiosync_set_feed(const double *source, size_t source_len,
                               const double *sample, size_t sample_len,
                               unsigned frames_per_ms);
 
+/* The same from two files or FIFOs of f64le mono frames at SAMPLE_RATE -- the wire format the
+ * reference's producers read from their ffmpeg children (`-f f64le`, src/capture/linux_capture.c:370,
+ * src/download/linux_download.c:41; chunked reads of src/ffmpeg_pipe.c:68-81).  source_path is the
+ * downloaded track (up to 2*30 s are read), sample_path the recorded one (up to 30 s); a short file is
+ * zero-filled.  A path that cannot be opened aborts the run like a failed ffmpeg child.  Returns 0, or
+ * -1 for a NULL path. */
+extern int audiosync_set_feed_files(const char *source_path, const char *sample_path);
+
 /* Debug aid replacing the reference's compile-time PLOT/gnuplot dumps
  * (src/cross_correlation.c:168-184,280-296): writes the two segments that
  * pearson_coefficient() compares for `lag` (src/cross_correlation.c:256-271) as

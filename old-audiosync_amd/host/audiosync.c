@@ -17,12 +17,15 @@
  * last one and reuses the plan of its length.  Result and error behaviour per
  * interval are those of cross_correlation().
  */
+#include <errno.h>
+#include <fcntl.h>
 #include <math.h>
 #include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#include <unistd.h>
 
 #include <audiosync/audiosync.h>
 #include <audiosync/cross_correlation.h>
@@ -114,21 +117,51 @@ int audiosync_setup(const char *stream_name)
     return -1;
 }
 
-/* ---- in-memory producers --------------------------------------------------- */
+/* ---- producers: from caller memory, or f64le frames from a file / FIFO ------- */
 struct feed {
-    const double *data;
+    const double *data;   /* in-memory track (audiosync_set_feed), or NULL */
     size_t len;
+    char *path;           /* file or FIFO of f64le mono frames (audiosync_set_feed_files), or NULL */
 };
 static struct feed feed_source, feed_sample;
 static unsigned feed_frames_per_ms;
+
+static void feed_clear(struct feed *f)
+{
+    free(f->path);
+    f->data = NULL; f->len = 0; f->path = NULL;
+}
 
 int audiosync_set_feed(const double *source, size_t source_len, const double *sample,
                        size_t sample_len, unsigned frames_per_ms)
 {
     pthread_mutex_lock(&mutex);
+    feed_clear(&feed_source); feed_clear(&feed_sample);
     feed_source.data = source; feed_source.len = source_len;
     feed_sample.data = sample; feed_sample.len = sample_len;
     feed_frames_per_ms = frames_per_ms;
+    pthread_mutex_unlock(&mutex);
+    return 0;
+}
+
+/* The wire format of the reference's producers: what `ffmpeg ... -f f64le -ac 1 -ar 48000 pipe:1`
+ * writes (src/capture/linux_capture.c:370, src/download/linux_download.c:41) and src/ffmpeg_pipe.c:68-81
+ * reads in chunks.  Each path may be a regular file or a FIFO an ffmpeg process is writing to; the
+ * producers read it in the same 4096-frame steps with the same signalling.  Returns -1 if a path is NULL. */
+int audiosync_set_feed_files(const char *source_path, const char *sample_path)
+{
+    if (source_path == NULL || sample_path == NULL) return -1;
+    char *a = strdup(source_path), *b = strdup(sample_path);
+    if (a == NULL || b == NULL) {
+        perror("audiosync: strdup for the feed paths failed");
+        free(a); free(b);
+        return -1;
+    }
+    pthread_mutex_lock(&mutex);
+    feed_clear(&feed_source); feed_clear(&feed_sample);
+    feed_source.path = a;
+    feed_sample.path = b;
+    feed_frames_per_ms = 0;
     pthread_mutex_unlock(&mutex);
     return 0;
 }
@@ -139,16 +172,56 @@ struct producer_args {
     unsigned frames_per_ms;
 };
 
+/* reads up to `want` bytes; returns the bytes read (short only at end of file), -1 on error */
+static ssize_t read_fully(int fd, void *dst, size_t want)
+{
+    size_t got = 0;
+    while (got < want) {
+        const ssize_t r = read(fd, (char *) dst + got, want - got);
+        if (r < 0) {
+            if (errno == EINTR) continue;
+            return -1;
+        }
+        if (r == 0) break;
+        got += (size_t) r;
+    }
+    return (ssize_t) got;
+}
+
 static void *producer(void *arg)
 {
     struct producer_args *pa = arg;
     struct ffmpeg_data *d = pa->out;
     size_t interval = 0;
-    const size_t avail = pa->in.data ? (pa->in.len < d->total_len ? pa->in.len : d->total_len) : 0;
+    int fd = -1;
+    size_t avail = pa->in.data ? (pa->in.len < d->total_len ? pa->in.len : d->total_len) : 0;
+    if (pa->in.path) {
+        fd = open(pa->in.path, O_RDONLY);
+        if (fd < 0) {
+            /* like a failed ffmpeg child (src/ffmpeg_pipe.c:59-62): the job is aborted */
+            perror("audiosync: open of the feed file failed");
+            audiosync_abort();
+            return NULL;
+        }
+        avail = d->total_len;
+    }
 
     while (d->len < avail) {
         size_t step = avail - d->len < FEED_STEP ? avail - d->len : FEED_STEP;
+        if (fd >= 0) {
+            /* src/ffmpeg_pipe.c:68-81: one chunk of f64le frames; end of file ends the track */
+            const ssize_t got = read_fully(fd, d->buf + d->len, step * sizeof(*d->buf));
+            if (got < 0) {
+                perror("audiosync: read of the feed file failed");
+                close(fd);
+                audiosync_abort();
+                return NULL;
+            }
+            step = (size_t) got / sizeof(*d->buf);
+            if (step == 0) break;
+        } else {
         memcpy(d->buf + d->len, pa->in.data + d->len, step * sizeof(*d->buf));
+        }
         if (pa->frames_per_ms) {
             struct timespec ts = { 0, (long)(1000000.0 * step / pa->frames_per_ms) };
             nanosleep(&ts, NULL);
@@ -163,8 +236,12 @@ static void *producer(void *arg)
         while (global_status == PAUSED_ST) pthread_cond_wait(&read_continue, &mutex);
         const int stop = (global_status == ABORT_ST);
         pthread_mutex_unlock(&mutex);
-        if (stop) return NULL;
+        if (stop) {
+            if (fd >= 0) close(fd);
+            return NULL;
+        }
     }
+    if (fd >= 0) close(fd);
     /* a short track: the tail reads as silence (src/ffmpeg_pipe.c:139-149) */
     if (d->len < d->total_len) {
         memset(d->buf + d->len, 0, (d->total_len - d->len) * sizeof(*d->buf));
@@ -207,9 +284,9 @@ int audiosync_run(const char *yt_title, long *lag)
     cap_pa.out = &cap_args; cap_pa.in = feed_sample; cap_pa.frames_per_ms = feed_frames_per_ms;
     down_pa.out = &down_args; down_pa.in = feed_source; down_pa.frames_per_ms = feed_frames_per_ms;
     pthread_mutex_unlock(&mutex);
-    if (cap_pa.in.data == NULL || down_pa.in.data == NULL) {
+    if ((cap_pa.in.data == NULL && cap_pa.in.path == NULL) || (down_pa.in.data == NULL && down_pa.in.path == NULL)) {
         /* nothing to record or download: the reference's producers fail and abort the job */
-        LOG("no feed configured (audiosync_set_feed); aborting");
+        LOG("no feed configured (audiosync_set_feed / audiosync_set_feed_files); aborting");
         goto finish;
     }
     if (pthread_create(&cap_th, NULL, &producer, &cap_pa) != 0) {

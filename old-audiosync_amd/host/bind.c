@@ -12,6 +12,7 @@
  *                                                                   (any C-contiguous buffers of that many
  *                                                                   float32 or float64 values; 1-D or 2-D)
  *   set_feed(source, sample, frames_per_ms=0)                      tracks that run() will consume
+ *   set_feed_files(source_path, sample_path)                       the same from f64le files / FIFOs
  * float64 goes through cross_correlation(double*) (transforms in float32, Pearson on the doubles);
  * float32 goes through asx_xcorr_batch_f32 (one launch group per call, the batched path of the benchmark).
  */
@@ -292,6 +293,24 @@ static PyObject *mod_set_feed(PyObject *self, PyObject *args)
     Py_RETURN_NONE;
 }
 
+static PyObject *mod_set_feed_files(PyObject *self, PyObject *args)
+{
+    UNUSED(self);
+    const char *src_path, *smp_path;
+    if (!PyArg_ParseTuple(args, "ss", &src_path, &smp_path)) return NULL;
+    if (audiosync_status() != IDLE_ST) {
+        PyErr_SetString(PyExc_RuntimeError, "set_feed_files() while a run is in progress");
+        return NULL;
+    }
+    if (audiosync_set_feed_files(src_path, smp_path) != 0) {
+        PyErr_SetString(PyExc_RuntimeError, "set_feed_files() failed");
+        return NULL;
+    }
+    free(feed_source_copy); free(feed_sample_copy);
+    feed_source_copy = NULL; feed_sample_copy = NULL;
+    Py_RETURN_NONE;
+}
+
 static PyMethodDef methods[] = {
     { "run", mod_run, METH_VARARGS, "run(title) -> (lag_ms, success). One run at a time." },
     { "pause", mod_pause, METH_NOARGS, "Pause the current run. Thread-safe." },
@@ -308,6 +327,9 @@ static PyMethodDef methods[] = {
       "samples [B][N], float32 (one batched launch) or float64 (the double ABI per pair)." },
     { "set_feed", mod_set_feed, METH_VARARGS,
       "set_feed(source, sample, frames_per_ms=0): the tracks run() will 'download' and 'record'." },
+    { "set_feed_files", mod_set_feed_files, METH_VARARGS,
+      "set_feed_files(source_path, sample_path): files or FIFOs of f64le mono frames at 48 kHz (what the "
+      "reference reads from `ffmpeg -f f64le`) that run() will consume." },
     { NULL, NULL, 0, NULL }
 };
 

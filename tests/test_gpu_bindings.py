@@ -107,3 +107,44 @@ def test_run_pause_resume_abort_state_machine(audiosync):
     lag_ms, ok = audiosync.run("again")
     assert ok is True and lag_ms == round(1000 * 1000.0 / 48000.0)
     assert audiosync.status() == "idle"
+
+
+def test_run_from_f64le_files_and_a_fifo(audiosync, tmp_path):
+    """the wire format of the reference's producers (`ffmpeg -f f64le`, src/ffmpeg_pipe.c:68-81): run() reads the two
+    tracks from files; a short sample file is zero-filled (src/ffmpeg_pipe.c:139-149); a FIFO written by another
+    thread works like the ffmpeg pipe; a missing file aborts the run"""
+    rng = np.random.default_rng(5)
+    source = rng.uniform(-1, 1, 2 * 30 * 48000)
+    delay = 2400                                                    # 50 ms
+    sample = 0.5 * source[delay: delay + 30 * 48000] + 0.01 * rng.uniform(-1, 1, 30 * 48000)
+    fsrc, fsmp = tmp_path / "source.f64le", tmp_path / "sample.f64le"
+    source.astype("<f8").tofile(fsrc)
+    sample.astype("<f8").tofile(fsmp)
+    audiosync.set_feed_files(str(fsrc), str(fsmp))
+    lag_ms, ok = audiosync.run("files")
+    assert ok is True and lag_ms == 50
+    # 4 s of sample only: the first interval (3 s) still resolves the delay
+    sample[: 4 * 48000].astype("<f8").tofile(fsmp)
+    audiosync.set_feed_files(str(fsrc), str(fsmp))
+    lag_ms, ok = audiosync.run("short")
+    assert ok is True and lag_ms == 50
+    # FIFO: a writer thread plays the role of the ffmpeg child
+    fifo = tmp_path / "sample.fifo"
+    os.mkfifo(fifo)
+    def writer():
+        try:
+            with open(fifo, "wb") as f:
+                f.write(sample.astype("<f8").tobytes())
+        except BrokenPipeError:
+            pass    # the run found the delay in the first interval and closed its end, like SIGKILL to ffmpeg
+    th = threading.Thread(target=writer)
+    th.start()
+    audiosync.set_feed_files(str(fsrc), str(fifo))
+    lag_ms, ok = audiosync.run("fifo")
+    assert ok is True and lag_ms == 50
+    th.join(timeout=30)
+    assert not th.is_alive()
+    # a file that does not exist: like a failed ffmpeg child, the job is aborted
+    audiosync.set_feed_files(str(tmp_path / "missing.f64le"), str(fsmp))
+    lag_ms, ok = audiosync.run("missing")
+    assert ok is False and audiosync.status() == "idle"
