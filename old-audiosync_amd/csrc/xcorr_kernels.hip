@@ -868,6 +868,17 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_inv_cols(const AsxDe
     const size_t stamp_block = pair * P.ntiles + tile;
     (void)stamp_block;
     ASX_STAMP_AT(2, stamp_block, 0);
+    // The pair's running maximum so far (other tiles publish theirs with atomicMax below) and the width
+    // of the near-maximum window are consumed after the first pass of the scan, at the very end.  Loaded where
+    // they are used, the block waits 2 700 cycles for an L2 round trip there (phase stamps).  Thread 0 fetches
+    // them now and parks them in LDS: its wave waits for them together with its tile loads, and everybody reads
+    // them behind the barriers of the transform.
+    __shared__ asx_peak_t s_run0;
+    __shared__ float s_b2;
+    if (threadIdx.x == 0) {
+        s_run0 = W.pairmax[pair];
+        s_b2 = W.bound2[pair];
+    }
     TwPre pre;
     if constexpr (STATIC) pre = tw_prefetch_first<S1, true, true, true>(Lc, P.tw1);
     else pre = tw_prefetch<true>(PD.st1, PD.st1.nstages - 1, Lc, P.tw1);
@@ -929,12 +940,10 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_inv_cols(const AsxDe
     }
     ASX_STAMP_AT(2, stamp_block, 2);
 
-    // The pair's running maximum so far (other tiles publish theirs with atomicMax below) and the width
-    // of the near-maximum window; both are consumed after the first pass of the scan.  ANY earlier value
-    // of the running maximum is a lower bound of the final one, so a stale read merely admits more
-    // candidates (k_finalize filters them against the final maximum).
-    const asx_peak_t run0 = W.pairmax[pair];
-    const float b2 = W.bound2[pair];
+    // ANY earlier value of the running maximum is a lower bound of the final one, so a stale read merely admits
+    // more candidates (k_finalize filters them against the final maximum).
+    const asx_peak_t run0 = s_run0;
+    const float b2 = s_b2;
     if constexpr (!STATIC) {
         // Run-time schedules (lengths outside the reference's six): r lies in LDS and is scanned there.  The
         // scan from the last stage's registers below, instantiated inside the switch over eleven radix bodies,
@@ -1082,6 +1091,7 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_inv_cols(const AsxDe
         const uint32_t hh = fabsf(gb.x) == best_m ? 0u : fabsf(gb.y) == best_m ? 1u : fabsf(gb.z) == best_m ? 2u : 3u;
         const uint32_t my_idx = best_i0 + hh;
         // wave maximum in registers, smallest lag among the lanes that hold it, one entry per wave
+        ASX_STAMP_AT(2, stamp_block, 4);
         const float wmax = wave_max_nonneg(fmaxf(best_m, 0.f));
         unsigned long long holders = __ballot(best_m == wmax);
         uint32_t widx = 0xFFFFFFFFu;
@@ -1100,6 +1110,7 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_inv_cols(const AsxDe
         // Second look: lags within the float32 error window of the largest key known so far.  Almost every
         // thread is below the threshold; the one that holds the maximum usually has no second slot near
         // it and examines just that slot; a thread with more runs its last stage again.
+        ASX_STAMP_AT(2, stamp_block, 5);
         const float thr = near_max_threshold(peak_key(peak_max(tb, run0)), b2);
         thr_again = thr;
         if (best_m >= thr) {
