@@ -18,10 +18,12 @@ dp = ctypes.POINTER(ctypes.c_double)
 L.cross_correlation.restype = ctypes.c_int
 L.cross_correlation.argtypes = [dp, dp, ctypes.c_size_t, ctypes.POINTER(ctypes.c_long), dp]
 PROD = [144000, 288000, 480000] if os.environ.get("FUZZ_BIG") == "1" else [144000, 288000]
+if os.environ.get("FUZZ_HUGE") == "1": PROD = [720000, 960000, 1440000]
 t0 = time.time(); trials = checked = 0
 while time.time() - t0 < budget:
     r = rng.uniform()
     if os.environ.get("FUZZ_BIG") == "1": r *= 0.5   # FUZZ_BIG=1: only the production and the large lengths
+    if os.environ.get("FUZZ_HUGE") == "1": r = 0.0   # FUZZ_HUGE=1: only 15 / 20 / 30 s (720 000, 960 000, 1 440 000)
     if r < 0.15: n = int(rng.choice(PROD))
     elif r < 0.35: n = int(rng.integers(20000, 300001))
     elif r < 0.5: n = int(rng.choice([48000, 44100, 96000, 65536, 100000, 131072, 250000]))
