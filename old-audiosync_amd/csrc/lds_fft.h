@@ -622,7 +622,9 @@ __device__ __forceinline__ void lds_stage_wavepair(float4 *lds, const LdsLayout 
             }
         };
         if constexpr (!INV) run(std::integral_constant<int, 0>{}); else run(std::integral_constant<int, 1>{});
-        // same wave, in-order LDS: the second stage reads what the first wrote once the writes are issued
+        // same wave: the second stage reads what the first wrote.  LDS executes a wave's operations in order;
+        // the explicit wait for the writes costs one LDS latency per transform and does not lean on that.
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
