@@ -121,21 +121,28 @@ __device__ __forceinline__ v2f operator*(float b, v2f a) { return v2f{ a.x * b, 
 struct Cx2 {
     v2f re, im;
 };
+// One complex value per thread ("single member"): the two-pass row kernel (rows2.hip) runs radix-30/40
+// butterflies, whose two-member form would not fit the register file.
+struct Cx1 {
+    float re, im;
+};
 
 __device__ __forceinline__ Cx2 operator+(Cx2 a, Cx2 b) { return Cx2{ a.re + b.re, a.im + b.im }; }
 __device__ __forceinline__ Cx2 operator-(Cx2 a, Cx2 b) { return Cx2{ a.re - b.re, a.im - b.im }; }
+__device__ __forceinline__ Cx1 operator+(Cx1 a, Cx1 b) { return Cx1{ a.re + b.re, a.im + b.im }; }
+__device__ __forceinline__ Cx1 operator-(Cx1 a, Cx1 b) { return Cx1{ a.re - b.re, a.im - b.im }; }
 // multiply by -i: (re, im) -> (im, -re);  by +i: (-im, re)
-__device__ __forceinline__ Cx2 mul_neg_i(Cx2 a) { return Cx2{ a.im, -a.re }; }
-__device__ __forceinline__ Cx2 mul_pos_i(Cx2 a) { return Cx2{ -a.im, a.re }; }
-template <bool INV> __device__ __forceinline__ Cx2 rot(Cx2 a) { return INV ? mul_pos_i(a) : mul_neg_i(a); }
+template <class C> __device__ __forceinline__ C mul_neg_i(C a) { return C{ a.im, -a.re }; }
+template <class C> __device__ __forceinline__ C mul_pos_i(C a) { return C{ -a.im, a.re }; }
+template <bool INV, class C> __device__ __forceinline__ C rot(C a) { return INV ? mul_pos_i(a) : mul_neg_i(a); }
 // by a scalar twiddle shared by both members: a * w, a * conj(w)
-__device__ __forceinline__ Cx2 mulw(Cx2 a, float2 w)
+template <class C> __device__ __forceinline__ C mulw(C a, float2 w)
 {
-    return Cx2{ a.re * w.x - a.im * w.y, a.re * w.y + a.im * w.x };
+    return C{ a.re * w.x - a.im * w.y, a.re * w.y + a.im * w.x };
 }
-__device__ __forceinline__ Cx2 mulwc(Cx2 a, float2 w)
+template <class C> __device__ __forceinline__ C mulwc(C a, float2 w)
 {
-    return Cx2{ a.re * w.x + a.im * w.y, a.im * w.x - a.re * w.y };
+    return C{ a.re * w.x + a.im * w.y, a.im * w.x - a.re * w.y };
 }
 // member-wise complex products (different twiddle per member)
 __device__ __forceinline__ Cx2 mul2(Cx2 a, Cx2 w) { return Cx2{ a.re * w.re - a.im * w.im, a.re * w.im + a.im * w.re }; }
@@ -151,13 +158,13 @@ __device__ __forceinline__ Cx2 lds_get(const float4 *p)
 __device__ __forceinline__ void lds_put(float4 *p, Cx2 v) { *p = make_float4(v.re.x, v.im.x, v.re.y, v.im.y); }
 
 // a * w_R^M (forward) or a * conj(w_R^M) (INV), compile-time root
-template <int R, int M, bool INV> __device__ __forceinline__ Cx2 mul_root(Cx2 a)
+template <int R, int M, bool INV, class C> __device__ __forceinline__ C mul_root(C a)
 {
     constexpr int m = ((M % R) + R) % R;
     if constexpr (m == 0) {
         return a;
     } else if constexpr (2 * m == R) {
-        return Cx2{ -a.re, -a.im };
+        return C{ -a.re, -a.im };
     } else if constexpr (4 * m == R) { // w = -i ; conj = +i
         return INV ? mul_pos_i(a) : mul_neg_i(a);
     } else if constexpr (4 * m == 3 * R) { // w = +i
@@ -165,28 +172,29 @@ template <int R, int M, bool INV> __device__ __forceinline__ Cx2 mul_root(Cx2 a)
     } else {
         constexpr float c = Root<R, m>::re;
         constexpr float s = INV ? -Root<R, m>::im : Root<R, m>::im;
-        return Cx2{ a.re * c - a.im * s, a.re * s + a.im * c };
+        return C{ a.re * c - a.im * s, a.re * s + a.im * c };
     }
 }
 
 // ---- radix butterflies: v <- DFT_R(v) in natural order (INV: conjugate kernel, unnormalised) ----
+// run() is generic in the element type: Cx2 (two transforms per thread) or Cx1 (one).
 template <int R, bool INV> struct Bfly;
 
 template <bool INV> struct Bfly<2, INV> {
-    static __device__ __forceinline__ void run(Cx2 (&v)[2])
+    template <class C> static __device__ __forceinline__ void run(C (&v)[2])
     {
-        const Cx2 a = v[0], b = v[1];
+        const C a = v[0], b = v[1];
         v[0] = a + b;
         v[1] = a - b;
     }
 };
 
 template <bool INV> struct Bfly<4, INV> {
-    static __device__ __forceinline__ void run(Cx2 (&v)[4])
+    template <class C> static __device__ __forceinline__ void run(C (&v)[4])
     {
-        const Cx2 s0 = v[0] + v[2], d0 = v[0] - v[2];
-        const Cx2 s1 = v[1] + v[3], d1 = v[1] - v[3];
-        const Cx2 r = rot<INV>(d1); // forward: -i*d1 ; inverse: +i*d1
+        const C s0 = v[0] + v[2], d0 = v[0] - v[2];
+        const C s1 = v[1] + v[3], d1 = v[1] - v[3];
+        const C r = rot<INV>(d1); // forward: -i*d1 ; inverse: +i*d1
         v[0] = s0 + s1;
         v[2] = s0 - s1;
         v[1] = d0 + r;
@@ -195,13 +203,13 @@ template <bool INV> struct Bfly<4, INV> {
 };
 
 template <bool INV> struct Bfly<3, INV> {
-    static __device__ __forceinline__ void run(Cx2 (&v)[3])
+    template <class C> static __device__ __forceinline__ void run(C (&v)[3])
     {
         constexpr float sn = 0.86602540378443864676f; // sin(2*pi/3)
-        const Cx2 t1 = v[1] + v[2], t2 = v[1] - v[2];
-        const Cx2 m = Cx2{ v[0].re - 0.5f * t1.re, v[0].im - 0.5f * t1.im };
-        const Cx2 st = Cx2{ sn * t2.re, sn * t2.im };
-        const Cx2 r = rot<INV>(st);
+        const C t1 = v[1] + v[2], t2 = v[1] - v[2];
+        const C m = C{ v[0].re - 0.5f * t1.re, v[0].im - 0.5f * t1.im };
+        const C st = C{ sn * t2.re, sn * t2.im };
+        const C r = rot<INV>(st);
         v[0] = v[0] + t1;
         v[1] = m + r;
         v[2] = m - r;
@@ -209,18 +217,18 @@ template <bool INV> struct Bfly<3, INV> {
 };
 
 template <bool INV> struct Bfly<5, INV> {
-    static __device__ __forceinline__ void run(Cx2 (&v)[5])
+    template <class C> static __device__ __forceinline__ void run(C (&v)[5])
     {
         constexpr float c1 = 0.30901699437494742410f, s1 = 0.95105651629515357212f;
         constexpr float c2 = -0.80901699437494742410f, s2 = 0.58778525229247312917f;
-        const Cx2 a1 = v[1] + v[4], b1 = v[1] - v[4];
-        const Cx2 a2 = v[2] + v[3], b2 = v[2] - v[3];
-        const Cx2 m1 = Cx2{ v[0].re + c1 * a1.re + c2 * a2.re, v[0].im + c1 * a1.im + c2 * a2.im };
-        const Cx2 m2 = Cx2{ v[0].re + c2 * a1.re + c1 * a2.re, v[0].im + c2 * a1.im + c1 * a2.im };
-        const Cx2 u1 = Cx2{ s1 * b1.re + s2 * b2.re, s1 * b1.im + s2 * b2.im };
-        const Cx2 u2 = Cx2{ s2 * b1.re - s1 * b2.re, s2 * b1.im - s1 * b2.im };
-        const Cx2 r1 = rot<INV>(u1), r2 = rot<INV>(u2); // forward: -i*u ; inverse: +i*u
-        v[0] = Cx2{ v[0].re + a1.re + a2.re, v[0].im + a1.im + a2.im };
+        const C a1 = v[1] + v[4], b1 = v[1] - v[4];
+        const C a2 = v[2] + v[3], b2 = v[2] - v[3];
+        const C m1 = C{ v[0].re + c1 * a1.re + c2 * a2.re, v[0].im + c1 * a1.im + c2 * a2.im };
+        const C m2 = C{ v[0].re + c2 * a1.re + c1 * a2.re, v[0].im + c2 * a1.im + c1 * a2.im };
+        const C u1 = C{ s1 * b1.re + s2 * b2.re, s1 * b1.im + s2 * b2.im };
+        const C u2 = C{ s2 * b1.re - s1 * b2.re, s2 * b1.im - s1 * b2.im };
+        const C r1 = rot<INV>(u1), r2 = rot<INV>(u2); // forward: -i*u ; inverse: +i*u
+        v[0] = C{ v[0].re + a1.re + a2.re, v[0].im + a1.im + a2.im };
         v[1] = m1 + r1;
         v[4] = m1 - r1;
         v[2] = m2 + r2;
@@ -233,12 +241,12 @@ template <bool INV> struct Bfly<5, INV> {
 //   w_R^(t*u) = w_R1^(t1*u1) * w_R^(t2*u1) * w_R2^(t2*u2)
 template <int R1, int R2, bool INV> struct BflyC {
     static constexpr int R = R1 * R2;
-    static __device__ __forceinline__ void run(Cx2 (&v)[R])
+    template <class C> static __device__ __forceinline__ void run(C (&v)[R])
     {
         // DFT_R1 over t1 for every t2, then the inner twiddle w_R^(t2*u1)
         static_for<0, R2>([&](auto T2) __attribute__((always_inline)) {
             constexpr int t2 = decltype(T2)::value;
-            Cx2 x[R1];
+            C x[R1];
             static_for<0, R1>([&](auto T1) __attribute__((always_inline)) { x[T1] = v[R2 * T1 + t2]; });
             Bfly<R1, INV>::run(x);
             static_for<0, R1>([&](auto U1) __attribute__((always_inline)) {
@@ -246,10 +254,10 @@ template <int R1, int R2, bool INV> struct BflyC {
             });
         });
         // DFT_R2 over t2 for every u1; outputs land in natural order u = u1 + R1*u2
-        Cx2 y[R];
+        C y[R];
         static_for<0, R1>([&](auto U1) __attribute__((always_inline)) {
             constexpr int u1 = decltype(U1)::value;
-            Cx2 x[R2];
+            C x[R2];
             static_for<0, R2>([&](auto T2) __attribute__((always_inline)) { x[T2] = v[R2 * u1 + T2]; });
             Bfly<R2, INV>::run(x);
             static_for<0, R2>([&](auto U2) __attribute__((always_inline)) { y[u1 + R1 * U2] = x[U2]; });
@@ -271,12 +279,12 @@ template <int R1, int R2, bool INV> struct BflyP {
             if (u % R1 == u1 && u % R2 == u2) return u;
         return 0;
     }
-    static __device__ __forceinline__ void run(Cx2 (&v)[R])
+    template <class C> static __device__ __forceinline__ void run(C (&v)[R])
     {
-        Cx2 a[R]; // a[R2*u1 + t2]
+        C a[R]; // a[R2*u1 + t2]
         static_for<0, R2>([&](auto T2) __attribute__((always_inline)) {
             constexpr int t2 = decltype(T2)::value;
-            Cx2 x[R1];
+            C x[R1];
             static_for<0, R1>([&](auto T1) __attribute__((always_inline)) {
                 x[T1] = v[(R2 * decltype(T1)::value + R1 * t2) % R];
             });
@@ -285,10 +293,13 @@ template <int R1, int R2, bool INV> struct BflyP {
         });
         static_for<0, R1>([&](auto U1) __attribute__((always_inline)) {
             constexpr int u1 = decltype(U1)::value;
-            Cx2 x[R2];
+            C x[R2];
             static_for<0, R2>([&](auto T2) __attribute__((always_inline)) { x[T2] = a[R2 * u1 + decltype(T2)::value]; });
             Bfly<R2, INV>::run(x);
-            static_for<0, R2>([&](auto U2) __attribute__((always_inline)) { v[crt(u1, decltype(U2)::value)] = x[U2]; });
+            static_for<0, R2>([&](auto U2) __attribute__((always_inline)) {
+                constexpr int u = crt(u1, decltype(U2)::value); // forced constant: a run-time crt() of radix 30/40 would index registers dynamically
+                v[u] = x[U2];
+            });
         });
     }
 };
@@ -300,6 +311,11 @@ template <bool INV> struct Bfly<10, INV> : BflyP<2, 5, INV> {};
 template <bool INV> struct Bfly<12, INV> : BflyP<3, 4, INV> {};
 template <bool INV> struct Bfly<15, INV> : BflyP<3, 5, INV> {};
 template <bool INV> struct Bfly<16, INV> : BflyC<4, 4, INV> {};
+// the radices of the two-pass row kernel (rows2.hip), single member only: prime-factor maps all the way down
+template <bool INV> struct Bfly<20, INV> : BflyP<4, 5, INV> {};
+template <bool INV> struct Bfly<24, INV> : BflyP<3, 8, INV> {};
+template <bool INV> struct Bfly<30, INV> : BflyP<5, 6, INV> {};
+template <bool INV> struct Bfly<40, INV> : BflyP<5, 8, INV> {};
 
 // ---------------------------------------------------------------------------
 // One stage.  The LDS image is an array of float4 slots; slot (g, e) = element e of the

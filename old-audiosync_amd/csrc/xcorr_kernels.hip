@@ -16,6 +16,7 @@
 // The transforms are memory-bound (about 6 flop/byte); nothing here uses MFMA.
 #include "asx_internal.h"
 #include "lds_fft.h"
+#include "xcorr_dev.h"
 
 #include <algorithm>
 #include <initializer_list>
@@ -74,44 +75,6 @@ __device__ __forceinline__ void asx_st16(float2 *p, float4 v, bool nt)
 
 extern __shared__ __attribute__((aligned(16))) float2 asx_lds[];
 
-// The scalars and table pointers of the plan a kernel uses, copied into registers ONCE at its
-// start.  Read through the plan pointer where they are used, every use after a barrier is another
-// scalar load plus a wait that also drains the LDS queue (the spectral combine of k_rows alone
-// re-read two pointers in each of its five steps).
-struct AsxKP {
-    const float2 *tw1, *tw2, *tw2s, *tw_lo, *tw_hi;
-    const int *pos2_of_k2;
-    uint32_t N, F, M, nout, src_valid, src_period;
-    int M1, M2, T, logT, ntiles;
-    unsigned long long *stamps;
-    int stamp_kernel;
-};
-__device__ __forceinline__ AsxKP asx_kp(const AsxDev &D)
-{
-    AsxKP k;
-    k.tw1 = D.tw1; k.tw2 = D.tw2; k.tw2s = D.tw2s; k.tw_lo = D.tw_lo; k.tw_hi = D.tw_hi;
-    k.pos2_of_k2 = D.pos2_of_k2;
-    k.N = D.N; k.F = D.F; k.M = D.M; k.nout = D.nout; k.src_valid = D.src_valid; k.src_period = D.src_period;
-    k.M1 = D.M1; k.M2 = D.M2; k.T = D.T; k.logT = D.logT; k.ntiles = D.ntiles;
-    k.stamps = D.stamps; k.stamp_kernel = D.stamp_kernel;
-    return k;
-}
-
-// w_F^p for p < F from the two-level table (one complex multiply, ~1.5e-7 accurate).
-__device__ __forceinline__ float2 tw_F(const AsxKP &P, uint32_t p)
-{
-    const float2 lo = P.tw_lo[p & (ASX_TW_LO - 1u)];
-    const float2 hi = P.tw_hi[p >> ASX_TW_LOG];
-    return cmul(lo, hi);
-}
-
-__device__ __forceinline__ float wave_sum_f32(float v)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
-
 // ---------------------------------------------------------------------------
 // Column tiles.  A tile is T columns (T even, a power of two) of the [M1][M2] matrix,
 // held in LDS as [M1][T/2] float4 slots; a slot is two adjacent columns as they lie in HBM,
@@ -156,7 +119,8 @@ constexpr int asx_ilog2(int v) { return v <= 1 ? 0 : 1 + asx_ilog2(v >> 1); }
 // S1 = void: column schedule, tile width and block size from the plan at run time (any length);
 // S1 = Sched<M1, radices...>, TC = tile width, NT = block size: compiled in (production lengths,
 // see the launchers).
-template <int MAXR, class S1 = void, int TC = 0, int NT = 0>
+// FS (compiled-in schedules only): the four-step twiddle w_M^(k1*j2) is applied here, to the outputs of the last stage.
+template <int MAXR, class S1 = void, int TC = 0, int NT = 0, bool FS = false>
 __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_fwd_cols(const AsxDev *__restrict__ Pp,
                                                                       const float *__restrict__ src,
                                                                       const float *__restrict__ smp,
@@ -287,7 +251,23 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_fwd_cols(const AsxDe
     if ((threadIdx.x & 63) == 0) nrm_red[threadIdx.x >> 6] = ss;
     __syncthreads();
     ASX_STAMP_AT(1, stamp_block, 1);
-    if constexpr (STATIC) lds_fft_static<S1, false, true>(lds4, Lc, P.tw1, pre);
+    if constexpr (STATIC && FS) {
+        // every stage but the last; the last one's outputs get the four-step twiddle in registers and are then
+        // written to their slots: rows pos0 .. pos0+R-1 of column pair g hold k1 = kb + (M1/R)*t
+        const TwPre pre_last = lds_fft_static_head<S1, false, true>(lds4, Lc, P.tw1, pre);
+        lds_last_stage_static<S1, false, true>(lds4, Lc, P.tw1, pre_last,
+            [&](auto RC, auto &v, int g, int pos0, int q) __attribute__((always_inline)) {
+                constexpr int R = decltype(RC)::value;
+                Cx2 fs[R];
+                fourstep_tw<R>(P, (uint32_t)P.k1_of_pos1[pos0], (uint32_t)(S1::n / R), (uint32_t)(c0 + 2 * g), fs);
+                float4 *p = lds4 + g * Lc.group_stride + pos0 * Lc.elem_stride;
+                static_for<0, R>([&](auto TT) __attribute__((always_inline)) {
+                    constexpr int t = decltype(TT)::value;
+                    lds_put(p + t * q * Lc.elem_stride, mul2(v[t], fs[t]));
+                });
+            });
+        __syncthreads();
+    } else if constexpr (STATIC) lds_fft_static<S1, false, true>(lds4, Lc, P.tw1, pre);
     else lds_fft<MAXR, false, true>(lds4, PD.st1, Lc, P.tw1, pre);
     }
     ASX_STAMP_AT(1, stamp_block, 2);
@@ -329,26 +309,6 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_fwd_cols(const AsxDe
 // the two rows of G, which the inverse transforms as one pair.  Self-paired rows
 // (k1 = 0, M1/2) use A only and carry zeros in the second member of C.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ void combine_pair(Cx2 Za, Cx2 Zb, float2 w2, float2 &Gk, float2 &Gm)
-{
-    // Za = (Zx[k], Zy[k]), Zb = (Zx[M-k], Zy[M-k]); w2 = w_M^k.  With E' = a + conj b and
-    // O' = -i (a - conj b) (twice the even/odd parts of the real-FFT untangling), X[k] = (E'x + w O'x)/2
-    // etc.  Expanding P = X conj(Y) (src/cross_correlation.c:232-233) for k and M-k and the inverse
-    // tangling G[k] = (P[k] + conj P[M-k]) + i conj(w)(P[k] - conj P[M-k]) collapses to
-    //     W = E'x conj(E'y) + O'x conj(O'y),   U = O'x conj(E'y) + conj(w^2) E'x conj(O'y)
-    //     G[k] = (W + i U)/2,   G[M-k] = (conj W + i conj U)/2
-    // (checked against the step-by-step form in tests/model_fourstep.py): 40 real operations
-    // per pair of bins instead of 60, and X, Y, P never exist.
-    const Cx2 E = Cx2{ Za.re + Zb.re, Za.im - Zb.im };
-    const Cx2 O = Cx2{ Za.im + Zb.im, Zb.re - Za.re };
-    const float2 Ex = make_float2(E.re.x, E.im.x), Ey = make_float2(E.re.y, E.im.y);
-    const float2 Ox = make_float2(O.re.x, O.im.x), Oy = make_float2(O.re.y, O.im.y);
-    const float2 W = cadd(cmulc(Ex, Ey), cmulc(Ox, Oy));
-    const float2 U = cadd(cmulc(Ox, Ey), cmulc(cmulc(Ex, Oy), w2));
-    Gk = make_float2(0.5f * (W.x - U.y), 0.5f * (W.y + U.x));
-    Gm = make_float2(0.5f * (W.x + U.y), 0.5f * (U.x - W.y));
-}
-
 // Row loads of one task, all issued before the first is consumed.  (Issuing them one task
 // AHEAD in a persistent block was tried: +50 live VGPRs pushed k_rows to 221 registers = two
 // waves per SIMD, and the kernel got 1.6x slower; see DESIGN.md "what did not work".)
@@ -839,7 +799,8 @@ __device__ __forceinline__ void cand_append(const AsxPeakWs &W, size_t pair, uin
     }
 }
 
-template <int MAXR, class S1 = void, int TC = 0, int NT = 0>
+// FS (compiled-in schedules, full tiles): the conjugate four-step twiddle is applied here, to the inputs of the first stage.
+template <int MAXR, class S1 = void, int TC = 0, int NT = 0, bool FS = false>
 __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_inv_cols(const AsxDev *__restrict__ Pp, const float2 *__restrict__ ga,
                                                                    AsxPeakWs W, float *__restrict__ r_out)
 {
@@ -901,6 +862,12 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_inv_cols(const AsxDe
                         const float4 x = asx_ld16(col + (size_t)(t * q) * M2, ASX_NT & 16);
                         v[t] = Cx2{ v2f{ x.x, x.z }, v2f{ x.y, x.w } };
                     });
+                    if constexpr (FS) { // q == 1: rows pos0 .. pos0+R-1 hold k1 = kb + (M1/R)*t
+                        constexpr int R = decltype(RC)::value;
+                        Cx2 fs[R];
+                        fourstep_tw<R>(P, (uint32_t)P.k1_of_pos1[pos0], (uint32_t)(S1::n / R), (uint32_t)(c0 + 2 * g), fs);
+                        static_for<0, R>([&](auto TT) __attribute__((always_inline)) { v[TT] = mul2c(v[TT], fs[TT]); });
+                    }
                 });
             filled = true;
         }
@@ -1597,6 +1564,8 @@ bool asx_launch_inv_cols_static(const AsxDev &P, const float2 *ga, const AsxPeak
 void asx_launch_inv_cols_generic(const AsxDev &P, const float2 *ga, const AsxPeakWs &W, float *r_out, int npairs,
                                  hipStream_t s);
 
+// the four-step variants need full tiles (the fed first stage of k_inv_cols)
+static bool fourstep_ok(const AsxDev &P) { return P.M2 % P.T == 0 && (P.M2 & 1) == 0; }
 #define ASX_FWD_LAUNCH(...) \
     do { allow_big_lds((const void *)k_fwd_cols<__VA_ARGS__>, lds_bytes_cols(P)); \
          hipLaunchKernelGGL((k_fwd_cols<__VA_ARGS__>), grid, dim3(P.threads_cols), lds_bytes_cols(P), s, P.self_dev, src, smp, zxa, zya, W.nrm_part); } while (0)
@@ -1606,7 +1575,10 @@ bool asx_launch_fwd_cols_static(const AsxDev &P, const float *src, const float *
 {
     dim3 grid(col_grid_x(P.ntiles, P.logT), 2, npairs);
 #define ASX_TRY_STATIC(m1, t, nt, maxr, ...) \
-    if (P.T == (t) && P.threads_cols == (nt) && schedule_is(P.st1, m1, { __VA_ARGS__ })) { ASX_FWD_LAUNCH(maxr, Sched<m1, __VA_ARGS__>, t, nt); return true; }
+    if (P.T == (t) && P.threads_cols == (nt) && schedule_is(P.st1, m1, { __VA_ARGS__ })) { \
+        if (P.fs_in_cols) { if (!fourstep_ok(P)) return false; ASX_FWD_LAUNCH(maxr, Sched<m1, __VA_ARGS__>, t, nt, true); } \
+        else ASX_FWD_LAUNCH(maxr, Sched<m1, __VA_ARGS__>, t, nt, false); \
+        return true; }
     ASX_STATIC_COLS(ASX_TRY_STATIC)
 #undef ASX_TRY_STATIC
     return false;
@@ -1684,7 +1656,10 @@ bool asx_launch_inv_cols_static(const AsxDev &P, const float2 *ga, const AsxPeak
 {
     dim3 grid(col_grid_x(P.ntiles, P.logT), npairs);
 #define ASX_TRY_STATIC(m1, t, nt, maxr, ...) \
-    if (P.T == (t) && P.threads_cols == (nt) && schedule_is(P.st1, m1, { __VA_ARGS__ })) { ASX_INV_LAUNCH(maxr, Sched<m1, __VA_ARGS__>, t, nt); return true; }
+    if (P.T == (t) && P.threads_cols == (nt) && schedule_is(P.st1, m1, { __VA_ARGS__ })) { \
+        if (P.fs_in_cols) { if (!fourstep_ok(P)) return false; ASX_INV_LAUNCH(maxr, Sched<m1, __VA_ARGS__>, t, nt, true); } \
+        else ASX_INV_LAUNCH(maxr, Sched<m1, __VA_ARGS__>, t, nt, false); \
+        return true; }
     ASX_STATIC_COLS(ASX_TRY_STATIC)
 #undef ASX_TRY_STATIC
     return false;
@@ -1738,6 +1713,16 @@ static bool generic_only()
     return g;
 }
 
+bool asx_cols_have_fourstep(const AsxDev &P)
+{
+    if (generic_only() || !fourstep_ok(P)) return false;
+#define ASX_TRY_STATIC(m1, t, nt, maxr, ...) \
+    if (P.T == (t) && P.threads_cols == (nt) && schedule_is(P.st1, m1, { __VA_ARGS__ })) return true;
+    ASX_STATIC_COLS(ASX_TRY_STATIC)
+#undef ASX_TRY_STATIC
+    return false;
+}
+
 void asx_launch_fwd_cols(const AsxDev &P, const float *src, const float *smp, float2 *zxa,
                          float2 *zya, const AsxPeakWs &W, int npairs, hipStream_t s)
 {
@@ -1748,6 +1733,7 @@ void asx_launch_fwd_cols(const AsxDev &P, const float *src, const float *smp, fl
 void asx_launch_rows(const AsxDev &P, const float2 *zxa, const float2 *zya, float2 *ga,
                      const AsxPeakWs &W, int npairs, hipStream_t s)
 {
+    if (!generic_only() && asx_launch_rows2(P, zxa, zya, ga, W, npairs, s)) return; // two LDS passes per transform
     if (generic_only() || !asx_launch_rows_static(P, zxa, zya, ga, W, npairs, s))
         asx_launch_rows_generic(P, zxa, zya, ga, W, npairs, s);
 }
