@@ -172,9 +172,9 @@ static int plan_init(asx_plan *p, size_t N, size_t max_batch, const char *split)
     d.st1 = h.st1; d.st2 = h.st2;
     d.tw2r = nullptr;
     d.rows2_ra = d.rows2_rb = 0;
-    d.fs_in_cols = 0;
-    // diagnostics: ASX_ROWS2_OFF=1 keeps the three-pass row kernel, ASX_FS_IN_COLS=0 the four-step twiddles in the row kernel
-    if (!h.tw2r.empty() && !getenv("ASX_ROWS2_OFF") && !getenv("ASX_GENERIC")) {
+    // The two-pass row kernel (rows2.hip) is opt-in, ASX_ROWS2=1: measured equal to the three-pass k_rows on the
+    // headline length (1.16-1.18 ms against 1.14-1.15 ms per 124 pairs), so the default stays.
+    if (!h.tw2r.empty() && getenv("ASX_ROWS2") && atoi(getenv("ASX_ROWS2")) != 0 && !getenv("ASX_GENERIC")) {
         d.rows2_ra = h.rows2_ra; d.rows2_rb = h.rows2_rb;
         if (dev_upload(p, &d.tw2r, h.tw2r)) return -1;
     }
@@ -182,10 +182,6 @@ static int plan_init(asx_plan *p, size_t N, size_t max_batch, const char *split)
     d.threads_rows = asx_pick_threads(h.st2, 2, (h.M2 + ASX_ROW_STEPS - 1) / ASX_ROW_STEPS, asx_lds_bytes_rows(d));
     if (const char *e = getenv("ASX_THREADS_COLS")) d.threads_cols = atoi(e);
     if (const char *e = getenv("ASX_THREADS_ROWS")) d.threads_rows = atoi(e);
-    {
-        const char *e = getenv("ASX_FS_IN_COLS");
-        d.fs_in_cols = (d.tw2r && asx_cols_have_fourstep(d) && !(e && atoi(e) == 0)) ? 1 : 0;
-    }
     if (dev_upload(p, &d.tw1, h.tw1) || dev_upload(p, &d.tw2, h.tw2) || dev_upload(p, &d.tw2s, h.tw2s) || dev_upload(p, &d.tw_lo, h.tw_lo) ||
         dev_upload(p, &d.tw_hi, h.tw_hi) ||
         dev_upload(p, &d.k1_of_pos1, h.k1_of_pos1) || dev_upload(p, &d.pos1_of_k1, h.pos1_of_k1) ||

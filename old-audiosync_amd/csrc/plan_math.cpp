@@ -274,8 +274,9 @@ std::string asx_host_plan_build(size_t N, const char *split_override, AsxHostPla
     hp->tw2r.clear();
     hp->rows2_ra = hp->rows2_rb = 0;
     static const struct { int m2, ra, rb; } kRows2[] = { { 1200, 30, 40 } };
-    for (const auto &c : kRows2)
+    for (auto c : kRows2)
         if (c.m2 == M2) {
+            if (getenv("ASX_ROWS2_SWAP")) std::swap(c.ra, c.rb); // diagnostic: the factors the other way round
             hp->rows2_ra = c.ra; hp->rows2_rb = c.rb;
             hp->tw2r.resize(M2);
             for (int u = 0; u < c.ra; u++)

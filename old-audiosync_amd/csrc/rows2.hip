@@ -84,7 +84,9 @@ template <int R, bool NOBASE> __device__ __forceinline__ void rows2_twiddles(con
     });
 }
 
-// FSX: the four-step twiddles are applied by the column kernels (AsxDev::fs_in_cols), none here.
+// FSX (diagnostic, wrong results): no four-step twiddles, as if the column kernels applied them.  Measured: k_rows2
+// 1.17 -> 1.03 ms, but the same work costs k_fwd_cols +0.17 ms and k_inv_cols +0.07 ms (their VALU is not idle either):
+// tools/experiments/fourstep_in_cols.patch.
 template <int RA, int RB, int NT, bool FSX>
 __global__ __launch_bounds__(NT, ASX_ROWS2_WAVES) void k_rows2(const AsxDev *__restrict__ Pp, const float2 *__restrict__ zxa,
                                                                 const float2 *__restrict__ zya, float2 *__restrict__ ga,
@@ -92,7 +94,8 @@ __global__ __launch_bounds__(NT, ASX_ROWS2_WAVES) void k_rows2(const AsxDev *__r
                                                                 AsxPeakWs W)
 {
     constexpr int M2 = RA * RB, PT = RB + 1, RS = RA * PT; // row pitch and row-region size in float2 slots
-    static_assert(RB % 2 == 0, "the pitch RB + 1 is conflict-free for even RB");
+    // pass 2 strides 2*PT dwords from lane to lane: 32 distinct even banks for any odd... PT = RB + 1 with RB even
+    static_assert(RB % 2 == 0, "the pitch RB + 1 must be odd");
     const AsxDev &PD = *Pp;
     const AsxKP P = asx_kp(PD);
     const int nrows = M1 / 2 + 1;
@@ -193,39 +196,34 @@ __global__ __launch_bounds__(NT, ASX_ROWS2_WAVES) void k_rows2(const AsxDev *__r
         // no barrier between the reads and the writes.  Slot s = u*RB + v sits at u*PT + v, its mirror at
         // RS - 2 - (u*PT + v).
         constexpr int NP = M2 / 2, STEPS = (NP + NT - 1) / NT;
-        float2 w2a[STEPS], w2b[STEPS];
-        int ad[STEPS];
-        static_for<0, STEPS>([&](auto I) __attribute__((always_inline)) {
+        // steps whose 64 slots all lie past the end are skipped by the whole wave (the last step of most waves)
+        const int wave0 = tid & ~63;
+        auto step = [&](auto I) __attribute__((always_inline)) {
             constexpr int i = decltype(I)::value;
             int s = tid + i * NT;
-            s = s < NP ? s : 0; // clamped: the loads are unconditional
-            const int u = s / RB;
-            ad[i] = s + u; // u*PT + v
-            w2a[i] = PD.tw2r[s];
-            w2b[i] = PD.tw2r[M2 - 1 - s];
-        });
-        float2 xa0[STEPS], ya0[STEPS], xb1[STEPS], yb1[STEPS], xa1[STEPS], ya1[STEPS], xb0[STEPS], yb0[STEPS];
-        static_for<0, STEPS>([&](auto I) __attribute__((always_inline)) {
-            constexpr int i = decltype(I)::value;
-            const int a0 = ad[i], a1 = RS - 2 - ad[i];
-            xa0[i] = Xa[a0]; ya0[i] = Ya[a0]; xb1[i] = Xb[a1]; yb1[i] = Yb[a1];
-            xa1[i] = Xa[a1]; ya1[i] = Ya[a1]; xb0[i] = Xb[a0]; yb0[i] = Yb[a0];
-        });
-        static_for<0, STEPS>([&](auto I) __attribute__((always_inline)) {
-            constexpr int i = decltype(I)::value;
+            const bool mine = s < NP;
+            s = mine ? s : 0; // clamped: the loads are unconditional
+            const int a0 = s + s / RB, a1 = RS - 2 - a0; // u*PT + v and its mirror
+            const float2 w2a = PD.tw2r[s], w2b = PD.tw2r[M2 - 1 - s];
+            const float2 xa0 = Xa[a0], ya0 = Ya[a0], xb1 = Xb[a1], yb1 = Yb[a1];
+            const float2 xa1 = Xa[a1], ya1 = Ya[a1], xb0 = Xb[a0], yb0 = Yb[a0];
             float2 gk0, gm0, gk1, gm1;
-            if (ASX_R2_ABL & 8) { gk0 = xa0[i]; gm0 = yb1[i]; gk1 = xa1[i]; gm1 = yb0[i]; }
+            if (ASX_R2_ABL & 8) { gk0 = xa0; gm0 = yb1; gk1 = xa1; gm1 = yb0; }
             else {
-            combine_pair(Cx2{ v2f{ xa0[i].x, ya0[i].x }, v2f{ xa0[i].y, ya0[i].y } },
-                         Cx2{ v2f{ xb1[i].x, yb1[i].x }, v2f{ xb1[i].y, yb1[i].y } }, cmul(wA, w2a[i]), gk0, gm0);
-            combine_pair(Cx2{ v2f{ xa1[i].x, ya1[i].x }, v2f{ xa1[i].y, ya1[i].y } },
-                         Cx2{ v2f{ xb0[i].x, yb0[i].x }, v2f{ xb0[i].y, yb0[i].y } }, cmul(wA, w2b[i]), gk1, gm1);
+            combine_pair(Cx2{ v2f{ xa0.x, ya0.x }, v2f{ xa0.y, ya0.y } }, Cx2{ v2f{ xb1.x, yb1.x }, v2f{ xb1.y, yb1.y } },
+                         cmul(wA, w2a), gk0, gm0);
+            combine_pair(Cx2{ v2f{ xa1.x, ya1.x }, v2f{ xa1.y, ya1.y } }, Cx2{ v2f{ xb0.x, yb0.x }, v2f{ xb0.y, yb0.y } },
+                         cmul(wA, w2b), gk1, gm1);
             }
-            if (tid + i * NT < NP) {
-                const int a0 = ad[i], a1 = RS - 2 - ad[i];
+            if (mine) {
                 Xa[a0] = gk0; Xb[a1] = gm0; // G_k1 at slot s, G_m1 at slot s'
                 Xa[a1] = gk1; Xb[a0] = gm1;
             }
+        };
+        static_for<0, STEPS>([&](auto I) __attribute__((always_inline)) {
+            constexpr int i = decltype(I)::value;
+            if constexpr ((i + 1) * NT <= NP) step(I); // every wave has live slots
+            else if (wave0 + i * NT < NP) step(I);     // wave-uniform
         });
     } else {
         // Self-paired rows (k1 = 0, M1/2; two blocks per pair): bins pair up inside the row.  Every thread
@@ -326,18 +324,18 @@ bool asx_launch_rows2(const AsxDev &P, const float2 *zxa, const float2 *zya, flo
     const int ntasks = (P.M1 / 2 + 1) * npairs;
 #define ASX_ROWS2_CASE(ra, rb, nt)                                                                                      \
     if (P.rows2_ra == (ra) && P.rows2_rb == (rb)) {                                                                     \
-        if (P.fs_in_cols)                                                                                               \
-            hipLaunchKernelGGL((k_rows2<ra, rb, nt, true>), dim3(ntasks), dim3(nt), 0, s, P.self_dev, zxa, zya, ga,     \
-                               P.row_tasks, P.M1, P.M, W);                                                              \
-        else                                                                                                            \
-            hipLaunchKernelGGL((k_rows2<ra, rb, nt, false>), dim3(ntasks), dim3(nt), 0, s, P.self_dev, zxa, zya, ga,    \
-                               P.row_tasks, P.M1, P.M, W);                                                              \
+        hipLaunchKernelGGL((k_rows2<ra, rb, nt, ASX_ROWS2_FSX>), dim3(ntasks), dim3(nt), 0, s, P.self_dev, zxa, zya, ga,    \
+                           P.row_tasks, P.M1, P.M, W);                                                                  \
         return true;                                                                                                    \
     }
 #ifndef ASX_ROWS2_NT
 #define ASX_ROWS2_NT 192
 #endif
+#ifndef ASX_ROWS2_FSX
+#define ASX_ROWS2_FSX false
+#endif
     ASX_ROWS2_CASE(30, 40, ASX_ROWS2_NT)
+    ASX_ROWS2_CASE(40, 30, ASX_ROWS2_NT)
 #undef ASX_ROWS2_CASE
     return false;
 }

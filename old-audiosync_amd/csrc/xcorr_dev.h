@@ -10,7 +10,7 @@
 // re-read two pointers in each of its five steps).
 struct AsxKP {
     const float2 *tw1, *tw2, *tw2s, *tw_lo, *tw_hi;
-    const int *pos2_of_k2, *k1_of_pos1;
+    const int *pos2_of_k2;
     uint32_t N, F, M, nout, src_valid, src_period;
     int M1, M2, T, logT, ntiles;
     unsigned long long *stamps;
@@ -20,7 +20,7 @@ __device__ __forceinline__ AsxKP asx_kp(const AsxDev &D)
 {
     AsxKP k;
     k.tw1 = D.tw1; k.tw2 = D.tw2; k.tw2s = D.tw2s; k.tw_lo = D.tw_lo; k.tw_hi = D.tw_hi;
-    k.pos2_of_k2 = D.pos2_of_k2; k.k1_of_pos1 = D.k1_of_pos1;
+    k.pos2_of_k2 = D.pos2_of_k2;
     k.N = D.N; k.F = D.F; k.M = D.M; k.nout = D.nout; k.src_valid = D.src_valid; k.src_period = D.src_period;
     k.M1 = D.M1; k.M2 = D.M2; k.T = D.T; k.logT = D.logT; k.ntiles = D.ntiles;
     k.stamps = D.stamps; k.stamp_kernel = D.stamp_kernel;
@@ -40,27 +40,6 @@ __device__ __forceinline__ float wave_sum_f32(float v)
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
-}
-
-// Four-step twiddles of R consecutive row slots of one column pair (columns j2 and j2 + 1), member-wise:
-//     tw[t] = { w_M^(k_t * j2), w_M^(k_t * (j2 + 1)) },   k_t = kb + S * t
-// (the rows a column butterfly of the innermost stage touches hold frequencies S apart).  Plans with
-// AsxDev::fs_in_cols apply the four-step twiddle here, in the column kernels, whose VALU is mostly idle,
-// instead of in the row kernel, which is bound by its arithmetic.  k_t * j2 < M, so the
-// exponents of w_F = w_M^(1/2) stay below F.  A * B^t with the powers of B by squaring: depth <= 6 products.
-template <int R> __device__ __forceinline__ void fourstep_tw(const AsxKP &P, uint32_t kb, uint32_t S, uint32_t j2, Cx2 (&tw)[R])
-{
-    const float2 a0 = tw_F(P, 2u * kb * j2), a1 = cmul(a0, tw_F(P, 2u * kb));
-    const float2 b0 = tw_F(P, 2u * S * j2), b1 = cmul(b0, tw_F(P, 2u * S));
-    const Cx2 A = Cx2{ v2f{ a0.x, a1.x }, v2f{ a0.y, a1.y } };
-    Cx2 pw[R > 1 ? R : 2];
-    pw[1] = Cx2{ v2f{ b0.x, b1.x }, v2f{ b0.y, b1.y } };
-    static_for<2, R>([&](auto T) __attribute__((always_inline)) {
-        constexpr int t = decltype(T)::value;
-        pw[t] = (t % 2 == 0) ? mul2(pw[t / 2], pw[t / 2]) : mul2(pw[t - 1], pw[1]);
-    });
-    tw[0] = A;
-    static_for<1, R>([&](auto T) __attribute__((always_inline)) { tw[T] = mul2(A, pw[T]); });
 }
 
 // Spectral combine of one pair of bins (src/cross_correlation.c:232-233 between the real-FFT untangling of the

@@ -119,8 +119,7 @@ constexpr int asx_ilog2(int v) { return v <= 1 ? 0 : 1 + asx_ilog2(v >> 1); }
 // S1 = void: column schedule, tile width and block size from the plan at run time (any length);
 // S1 = Sched<M1, radices...>, TC = tile width, NT = block size: compiled in (production lengths,
 // see the launchers).
-// FS (compiled-in schedules only): the four-step twiddle w_M^(k1*j2) is applied here, to the outputs of the last stage.
-template <int MAXR, class S1 = void, int TC = 0, int NT = 0, bool FS = false>
+template <int MAXR, class S1 = void, int TC = 0, int NT = 0>
 __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_fwd_cols(const AsxDev *__restrict__ Pp,
                                                                       const float *__restrict__ src,
                                                                       const float *__restrict__ smp,
@@ -251,23 +250,7 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_fwd_cols(const AsxDe
     if ((threadIdx.x & 63) == 0) nrm_red[threadIdx.x >> 6] = ss;
     __syncthreads();
     ASX_STAMP_AT(1, stamp_block, 1);
-    if constexpr (STATIC && FS) {
-        // every stage but the last; the last one's outputs get the four-step twiddle in registers and are then
-        // written to their slots: rows pos0 .. pos0+R-1 of column pair g hold k1 = kb + (M1/R)*t
-        const TwPre pre_last = lds_fft_static_head<S1, false, true>(lds4, Lc, P.tw1, pre);
-        lds_last_stage_static<S1, false, true>(lds4, Lc, P.tw1, pre_last,
-            [&](auto RC, auto &v, int g, int pos0, int q) __attribute__((always_inline)) {
-                constexpr int R = decltype(RC)::value;
-                Cx2 fs[R];
-                fourstep_tw<R>(P, (uint32_t)P.k1_of_pos1[pos0], (uint32_t)(S1::n / R), (uint32_t)(c0 + 2 * g), fs);
-                float4 *p = lds4 + g * Lc.group_stride + pos0 * Lc.elem_stride;
-                static_for<0, R>([&](auto TT) __attribute__((always_inline)) {
-                    constexpr int t = decltype(TT)::value;
-                    lds_put(p + t * q * Lc.elem_stride, mul2(v[t], fs[t]));
-                });
-            });
-        __syncthreads();
-    } else if constexpr (STATIC) lds_fft_static<S1, false, true>(lds4, Lc, P.tw1, pre);
+    if constexpr (STATIC) lds_fft_static<S1, false, true>(lds4, Lc, P.tw1, pre);
     else lds_fft<MAXR, false, true>(lds4, PD.st1, Lc, P.tw1, pre);
     }
     ASX_STAMP_AT(1, stamp_block, 2);
@@ -799,8 +782,7 @@ __device__ __forceinline__ void cand_append(const AsxPeakWs &W, size_t pair, uin
     }
 }
 
-// FS (compiled-in schedules, full tiles): the conjugate four-step twiddle is applied here, to the inputs of the first stage.
-template <int MAXR, class S1 = void, int TC = 0, int NT = 0, bool FS = false>
+template <int MAXR, class S1 = void, int TC = 0, int NT = 0>
 __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_inv_cols(const AsxDev *__restrict__ Pp, const float2 *__restrict__ ga,
                                                                    AsxPeakWs W, float *__restrict__ r_out)
 {
@@ -814,6 +796,12 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_inv_cols(const AsxDe
     if constexpr (STATIC) { T = TC; logT = asx_ilog2(TC); M1 = S1::n; nthreads = NT; }
     const int tile = col_tile_of_block(blockIdx.x, logT);
     if (tile >= P.ntiles) return; // grid.x is rounded up (col_grid_x)
+    // A digitally silent track (a zero norm, e.g. the zero-filled tail of a short capture): r is exactly zero
+    // everywhere, the reference's scan returns index 0 (src/cross_correlation.c:52-67), which is what a running
+    // maximum left at zero means to k_finalize.  Without this every one of the 2N lags would be a near-tie of the
+    // maximum 0 inside a window of width 0, the lists would overflow and the synchronous entry points would
+    // re-evaluate all of them exactly (seconds at N = 1 440 000).  Block-uniform; r_out (tests) still wants zeros.
+    if (W.bound2[pair] == 0.f && r_out == nullptr) return;
     const int logH = logT - 1, H = T >> 1, M2 = P.M2;
     const int c0 = tile * T;
 #ifdef ASX_EXP_PAIRMOD
@@ -862,12 +850,6 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_inv_cols(const AsxDe
                         const float4 x = asx_ld16(col + (size_t)(t * q) * M2, ASX_NT & 16);
                         v[t] = Cx2{ v2f{ x.x, x.z }, v2f{ x.y, x.w } };
                     });
-                    if constexpr (FS) { // q == 1: rows pos0 .. pos0+R-1 hold k1 = kb + (M1/R)*t
-                        constexpr int R = decltype(RC)::value;
-                        Cx2 fs[R];
-                        fourstep_tw<R>(P, (uint32_t)P.k1_of_pos1[pos0], (uint32_t)(S1::n / R), (uint32_t)(c0 + 2 * g), fs);
-                        static_for<0, R>([&](auto TT) __attribute__((always_inline)) { v[TT] = mul2c(v[TT], fs[TT]); });
-                    }
                 });
             filled = true;
         }
@@ -1564,8 +1546,6 @@ bool asx_launch_inv_cols_static(const AsxDev &P, const float2 *ga, const AsxPeak
 void asx_launch_inv_cols_generic(const AsxDev &P, const float2 *ga, const AsxPeakWs &W, float *r_out, int npairs,
                                  hipStream_t s);
 
-// the four-step variants need full tiles (the fed first stage of k_inv_cols)
-static bool fourstep_ok(const AsxDev &P) { return P.M2 % P.T == 0 && (P.M2 & 1) == 0; }
 #define ASX_FWD_LAUNCH(...) \
     do { allow_big_lds((const void *)k_fwd_cols<__VA_ARGS__>, lds_bytes_cols(P)); \
          hipLaunchKernelGGL((k_fwd_cols<__VA_ARGS__>), grid, dim3(P.threads_cols), lds_bytes_cols(P), s, P.self_dev, src, smp, zxa, zya, W.nrm_part); } while (0)
@@ -1575,10 +1555,7 @@ bool asx_launch_fwd_cols_static(const AsxDev &P, const float *src, const float *
 {
     dim3 grid(col_grid_x(P.ntiles, P.logT), 2, npairs);
 #define ASX_TRY_STATIC(m1, t, nt, maxr, ...) \
-    if (P.T == (t) && P.threads_cols == (nt) && schedule_is(P.st1, m1, { __VA_ARGS__ })) { \
-        if (P.fs_in_cols) { if (!fourstep_ok(P)) return false; ASX_FWD_LAUNCH(maxr, Sched<m1, __VA_ARGS__>, t, nt, true); } \
-        else ASX_FWD_LAUNCH(maxr, Sched<m1, __VA_ARGS__>, t, nt, false); \
-        return true; }
+    if (P.T == (t) && P.threads_cols == (nt) && schedule_is(P.st1, m1, { __VA_ARGS__ })) { ASX_FWD_LAUNCH(maxr, Sched<m1, __VA_ARGS__>, t, nt); return true; }
     ASX_STATIC_COLS(ASX_TRY_STATIC)
 #undef ASX_TRY_STATIC
     return false;
@@ -1656,10 +1633,7 @@ bool asx_launch_inv_cols_static(const AsxDev &P, const float2 *ga, const AsxPeak
 {
     dim3 grid(col_grid_x(P.ntiles, P.logT), npairs);
 #define ASX_TRY_STATIC(m1, t, nt, maxr, ...) \
-    if (P.T == (t) && P.threads_cols == (nt) && schedule_is(P.st1, m1, { __VA_ARGS__ })) { \
-        if (P.fs_in_cols) { if (!fourstep_ok(P)) return false; ASX_INV_LAUNCH(maxr, Sched<m1, __VA_ARGS__>, t, nt, true); } \
-        else ASX_INV_LAUNCH(maxr, Sched<m1, __VA_ARGS__>, t, nt, false); \
-        return true; }
+    if (P.T == (t) && P.threads_cols == (nt) && schedule_is(P.st1, m1, { __VA_ARGS__ })) { ASX_INV_LAUNCH(maxr, Sched<m1, __VA_ARGS__>, t, nt); return true; }
     ASX_STATIC_COLS(ASX_TRY_STATIC)
 #undef ASX_TRY_STATIC
     return false;
@@ -1711,16 +1685,6 @@ static bool generic_only()
 {
     static const bool g = getenv("ASX_GENERIC") != nullptr; // diagnostic: never use the compiled-in schedules
     return g;
-}
-
-bool asx_cols_have_fourstep(const AsxDev &P)
-{
-    if (generic_only() || !fourstep_ok(P)) return false;
-#define ASX_TRY_STATIC(m1, t, nt, maxr, ...) \
-    if (P.T == (t) && P.threads_cols == (nt) && schedule_is(P.st1, m1, { __VA_ARGS__ })) return true;
-    ASX_STATIC_COLS(ASX_TRY_STATIC)
-#undef ASX_TRY_STATIC
-    return false;
 }
 
 void asx_launch_fwd_cols(const AsxDev &P, const float *src, const float *smp, float2 *zxa,

@@ -214,6 +214,29 @@ def test_zero_sample_returns_minus_one(mod):
     assert int(ret[0]) == o_ret == -1 and int(lag[0]) == o_lag == 0 and coef[0] != coef[0]
 
 
+@pytest.mark.parametrize("which", ["sample", "source", "both"])
+def test_silent_track_at_production_length_is_cheap(mod, which):
+    """A digitally silent capture (all zeros; the zero-filled tail of a short file) at N = 1 440 000: the reference
+    returns lag 0, a NaN coefficient and -1 in milliseconds (src/cross_correlation.c:52-67,276).  Every lag ties with
+    the maximum 0 then; the path must not take the second look over all 2N of them (seconds) -- ADVICE round 2."""
+    import time
+    n = 1440000
+    src, smp, _ = oracle.synth_pair(5, 0, n, 1)
+    src = src.astype(np.float64); smp = smp.astype(np.float64)
+    if which in ("sample", "both"):
+        smp[:] = 0.0
+    if which in ("source", "both"):
+        src[:] = 0.0
+    with mod.Plan(n, 1, 0) as plan:
+        plan.xcorr_f64(src, smp)          # warm-up: staging buffers, code objects
+        t0 = time.perf_counter()
+        ret, lag, coef = plan.xcorr_f64(src, smp)
+        dt = time.perf_counter() - t0
+        assert plan.peak_overflows() == 0 and plan.peak_repairs() == 0
+    assert ret == -1 and lag == 0 and coef != coef
+    assert dt < 0.25, dt                  # PCIe copy of 34.6 MB of doubles + the kernels: a few milliseconds
+
+
 def test_peak_at_index_n_gives_empty_segment(mod):
     n = 8
     src = np.zeros(2 * n); smp = np.zeros(n)
@@ -287,6 +310,40 @@ def test_full_size_planted_delay_and_oracle(mod, torch):
     src = d_src[: 2 * n].cpu().numpy(); smp = d_smp[:n].cpu().numpy()
     o_ret, o_lag, o_coef = oracle.cross_correlation(src, smp)
     assert o_ret == 0 and o_lag == int(d_lag[0]) and abs(o_coef - float(d_coef[0])) < COEF_TOL
+
+
+@pytest.mark.parametrize("n", [480000, 1440000])
+def test_two_pass_row_kernel_matches_oracle_and_default(mod, torch, monkeypatch, n):
+    """ASX_ROWS2=1 (read when a plan is created) selects k_rows2 (csrc/rows2.hip): the row kernel with one LDS exchange
+    per transform (1200 = 30 x 40, radix-30 / radix-40 butterflies) instead of three passes.  Same answers as the
+    default k_rows and as the oracle."""
+    batch = 4
+    d_src = torch.empty(batch * 2 * n, dtype=torch.float32, device="cuda")
+    d_smp = torch.empty(batch * n, dtype=torch.float32, device="cuda")
+    d_true = torch.empty(batch, dtype=torch.int64, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    mod.synth_pairs_dev(777, 0, batch, n, 0, d_src.data_ptr(), d_smp.data_ptr(), d_true.data_ptr(), stream)
+    got = {}
+    for label, flag in (("default", None), ("rows2", "1")):
+        if flag is None:
+            monkeypatch.delenv("ASX_ROWS2", raising=False)
+        else:
+            monkeypatch.setenv("ASX_ROWS2", flag)
+        d_lag = torch.empty(batch, dtype=torch.int64, device="cuda")
+        d_coef = torch.empty(batch, dtype=torch.float64, device="cuda")
+        d_ret = torch.empty(batch, dtype=torch.int32, device="cuda")
+        with mod.Plan(n, batch, 0) as plan:
+            assert plan.split[1] == 1200
+            plan.xcorr_batch_dev(d_src.data_ptr(), d_smp.data_ptr(), batch, d_lag.data_ptr(), d_coef.data_ptr(),
+                                 d_ret.data_ptr(), stream)
+            torch.cuda.synchronize()
+            assert plan.peak_overflows() == 0
+        assert torch.equal(d_lag, d_true) and int(d_ret.abs().sum()) == 0
+        got[label] = d_coef.cpu().numpy()
+    assert np.max(np.abs(got["default"] - got["rows2"])) < 1e-12   # same lag, same float64 Pearson pass
+    src = d_src[: 2 * n].cpu().numpy(); smp = d_smp[:n].cpu().numpy()
+    o_ret, o_lag, o_coef = oracle.cross_correlation(src, smp)
+    assert o_ret == 0 and o_lag == int(d_true[0]) and abs(o_coef - float(got["rows2"][0])) < COEF_TOL
 
 
 # ---- growing-window (streaming) mode: BASELINE config 5 --------------------------------------
