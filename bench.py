@@ -60,48 +60,122 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(sample_len, seconds_budget=20.0):
-    """The reference's CPU path on this node's host cores (oracle/cpu_baseline.c): (i) faithful single-call
-    latency -- two threads for the forward transforms, plans and allocations per call, the cost model of
-    src/cross_correlation.c:33-36,159-239; (ii) node throughput -- one independent single-threaded worker per
-    core over distinct pairs.  Backend: FFTW3 if libfftw3.so.3 can be dlopen()ed here, else the oracle's DFT."""
-    from concurrent.futures import ThreadPoolExecutor
+def cpu_quota():
+    """CPUs this process may actually use: the affinity mask, cut by the cgroup quota if there is one"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, int(q / per + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
+def _baseline_worker(n, pairs, rounds, first, ready, go, out):
     import oracle
-    cores = os.cpu_count() or 1
+    w = oracle.Worker(n)
+    w.run(*pairs[first % len(pairs)])          # touch every buffer once: page faults stay out of the timed region
+    ready.wait()
+    go.wait()
+    done = 0
+    for r in range(rounds):
+        ret, _, _ = w.run(*pairs[(first + r) % len(pairs)])
+        done += 1 if ret == 0 else 0
+    out.put(done)
+
+
+def _throughput(n, pairs, workers, rounds):
+    """`workers` independent single-threaded PROCESSES (one per core), each making `rounds` calls on its own buffers"""
+    import multiprocessing as mp
+    ctx = mp.get_context("fork")               # no GPU context exists in this process yet (see main())
+    ready, go, out = ctx.Barrier(workers + 1), ctx.Event(), ctx.Queue()
+    procs = [ctx.Process(target=_baseline_worker, args=(n, pairs, rounds, i, ready, go, out)) for i in range(workers)]
+    for p in procs:
+        p.start()
+    ready.wait()
+    t0 = time.perf_counter()
+    go.set()
+    done = sum(out.get() for _ in procs)
+    dt = time.perf_counter() - t0
+    for p in procs:
+        p.join()
+    return done / dt, dt, done
+
+
+def cpu_baseline(sample_len, seconds_budget=28.0):
+    """The reference's CPU path on this node's host cores (oracle/cpu_baseline.c), run BEFORE this process touches the
+    GPU.  (i) faithful single-call latency -- two threads for the forward transforms, plans and allocations per call, the
+    cost model of src/cross_correlation.c:33-36,159-239 -- at N and at BASELINE configs[0]'s N = 144 000; (ii) node
+    throughput -- independent single-threaded worker processes, one per core, plans and buffers kept between calls
+    (BASELINE.md section 4), swept over the worker count; `value` is the best point.  Backend: FFTW3 if libfftw3.so.3 can
+    be dlopen()ed here, else the oracle's own DFT (labelled)."""
+    import oracle
+    t_start = time.perf_counter()
+    cores, usable = os.cpu_count() or 1, cpu_quota()
     backend = oracle.baseline_backend()
-    workers = min(cores, 256)
-    distinct = min(workers, 16)
+    distinct = 8
     pairs = [oracle.synth_pair(1, p, sample_len, 1) for p in range(distinct)]
     pairs = [(s.astype("float64"), t.astype("float64")) for s, t, _ in pairs]
-    oracle.cross_correlation_faithful(pairs[0][0][: 2 * 4800], pairs[0][1][:4800])  # load the library
-    lat = []
-    for i in range(3):
-        t0 = time.perf_counter()
-        oracle.cross_correlation_faithful(*pairs[i % distinct])
-        lat.append(time.perf_counter() - t0)
-    one = statistics.median(lat)
-    rounds = max(1, min(4, int(seconds_budget / max(2.0 * one, 1e-3))))
+    small = oracle.synth_pair(1, 0, 144000, 1)
+    small = (small[0].astype("float64"), small[1].astype("float64"))
 
-    def work(i):
-        s, t = pairs[i % distinct]
-        for _ in range(rounds):
-            oracle.cross_correlation_faithful(s, t) if workers == 1 else oracle.cross_correlation(s, t)
-        return rounds
+    def latency(s, t, reps):
+        oracle.cross_correlation_faithful(s, t)
+        lat = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            oracle.cross_correlation_faithful(s, t)
+            lat.append(time.perf_counter() - t0)
+        return statistics.median(lat)
 
+    one = latency(*pairs[0], 3)
+    one_small = latency(*small, 5)
+    w1 = oracle.Worker(sample_len)
+    w1.run(*pairs[0])
     t0 = time.perf_counter()
-    with ThreadPoolExecutor(workers) as ex:
-        done = sum(ex.map(work, range(workers)))
-    dt = time.perf_counter() - t0
-    return {"value": done / dt, "unit": "cross-correlations/s", "cores": workers,
+    w1.run(*pairs[1])
+    t_worker = time.perf_counter() - t0
+    w1.close()
+    del w1
+    # sweep: powers of two up to the usable CPUs (and one step beyond: SMT siblings), best point wins
+    cands = sorted({c for c in (1, 2, 4, 8, 16, 32, 64, 128, 256, usable, min(2 * usable, cores)) if 1 <= c <= max(usable, min(2 * usable, cores))})
+    if len(cands) > 6:
+        cands = cands[-6:]
+    sweep, best = [], None
+    for wk in cands:
+        left = seconds_budget - (time.perf_counter() - t_start)
+        if left < 3.0 * t_worker + 1.0:
+            break
+        rounds = max(1, min(4, int(left / max(1, len(cands) - len(sweep)) / (2.0 * t_worker))))
+        rate, dt, done = _throughput(sample_len, pairs, wk, rounds)
+        sweep.append({"workers": wk, "calls": done, "seconds": round(dt, 3), "per_s": round(rate, 2)})
+        if best is None or rate > best[0]:
+            best = (rate, wk, done, dt)
+    rate, wk, done, dt = best
+    return {"value": rate, "unit": "cross-correlations/s", "cores": wk,
             "kind": "reference" if backend == "fftw3" else "port", "backend": backend,
-            "nproc": cores, "cpu_model": cpu_model(),
-            "single_call_latency_s": one,
+            "nproc": cores, "usable_cpus": usable, "cpu_model": cpu_model(), "sweep": sweep,
+            "single_call_latency_s": one, "single_call_latency_s_N144000": one_small,
+            "worker_call_s": t_worker,
             "single_call_model": "2 threads for the forward transforms, plan + 4 allocations per call "
                                  "(src/cross_correlation.c:33-36,159-239)",
-            "sample": "%d calls of N=%d (float32 values widened to float64) on %d workers = all %d logical cores, "
-                      "%d distinct pairs, %.1f s; backend %s" % (done, sample_len, workers, cores, distinct, dt,
-                                                                 "FFTW3 (dlopen libfftw3.so.3)" if backend == "fftw3"
-                                                                 else "oracle/fft64.c (no libfftw3 on this node)")}
+            "sample": "%d calls of N=%d (float32 values widened to float64) by %d single-threaded worker processes "
+                      "(plans and buffers kept per worker), %d distinct pairs, %.1f s, best of a sweep over the worker count; "
+                      "taken before the first GPU call; backend %s" %
+                      (done, sample_len, wk, distinct, dt,
+                       "FFTW3 (dlopen libfftw3.so.3)" if backend == "fftw3" else "oracle/fft64.c (no libfftw3 on this node)")}
 
 
 # --------------------------------------------------------------------------------------------------
@@ -279,9 +353,12 @@ class Workload:
             # on the same explicit stream, behind the kernels that produce them
             self.gathered = self.sharding.gather_result_buffers(self.res_buf, self.width, out=self.gather_out)
 
-    def timed(self, steps, warmup):
+    def timed(self, steps, warmup, precondition=0):
         torch, dist = self.torch, self.dist
-        for _ in range(warmup):
+        # `precondition` extra untimed steps BEFORE the W warm-up steps: after any host synchronisation the chip needs
+        # ~20 steps (~50 ms) to climb back to its working clock (k_rows 1.35 -> 1.10 ms, k_inv_cols 0.54 -> 0.40 ms over
+        # the first steps behind a synchronisation; profiles/r3_bench.json, kernel_ms_series), far more than W = 5 steps
+        for _ in range(precondition + warmup):
             self.step()
         torch.cuda.synchronize()
         if self.multi:
@@ -334,7 +411,8 @@ class Workload:
         rows = [self.plan.last_timings_ms(b) for b in range(steps)]
         self.plan.set_profiling(0)
         return ({k: statistics.median(r[k] for r in rows) for k in FAMILIES},
-                {k: [min(r[k] for r in rows), max(r[k] for r in rows)] for k in FAMILIES})
+                {k: [min(r[k] for r in rows), max(r[k] for r in rows)] for k in FAMILIES},
+                {k: [round(r[k], 4) for r in reversed(rows)] for k in ("fwd_cols", "rows", "inv_cols")})
 
     def close(self):
         self.plan.close()
@@ -345,11 +423,19 @@ def traffic_from_profiles(n, split, group, dom):
     """HBM bytes per launch of the dominant kernel from the committed PMC run (tools/traffic.sh: separate --pmc
     passes, FETCH_SIZE / WRITE_SIZE corrected as MI355X_MICROARCH.md prescribes) -- NOT measured in this run;
     only returned when that run was this workload (sample_len, split, group)."""
-    for name in ("r2_traffic.json", "r1_traffic.json"):
-        path = os.path.join(ROOT, "profiles", name)
-        if not os.path.exists(path):
+    import glob
+    import re
+    def round_of(path):
+        m = re.match(r"r(\d+)_", os.path.basename(path))
+        return int(m.group(1)) if m else 0
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic*.json")), key=round_of, reverse=True):
+        if "experiments" in path:
             continue
-        tj = json.load(open(path))
+        name = os.path.basename(path)
+        try:
+            tj = json.load(open(path))
+        except (OSError, ValueError):
+            continue
         c = tj.get("config", {})
         if c.get("sample_len") == n and c.get("split") == split and c.get("group") == group:
             for kname, kv in tj["kernels"].items():
@@ -358,7 +444,7 @@ def traffic_from_profiles(n, split, group, dom):
     return None, None
 
 
-def run_rank(args):
+def run_rank(args, cpu=None):
     import torch
     import torch.distributed as dist
     import __graft_entry__ as graft
@@ -397,9 +483,10 @@ def run_rank(args):
         n = args.sample_len
         batch = args.batch or max(8, min(4096, (2 << 30) // (12 * n)))   # ~2 GiB of inputs per GPU
         w = Workload(asx, sharding, torch, dist, dev, stream, n, batch * world, world, rank, multi, args.noise_shift, args.split)
-        dt = w.timed(args.steps, args.warmup)
+        pre = max(0, args.precondition - args.warmup)
+        dt = w.timed(args.steps, args.warmup, pre)
         ok = w.verify()
-        med, spread = w.kernel_medians(max(20, args.steps))
+        med, spread, series = w.kernel_medians(max(20, args.steps))
         plan_group, plan_split, plan_threads = w.plan.group, w.plan.split, w.plan.threads
         overflows = w.plan.peak_overflows()
         w.close()
@@ -450,13 +537,15 @@ def run_rank(args):
                          "frac": path_gbs / HBM_PEAK_GBS,
                          "basis": "52*N bytes per pair x pairs/s per GPU over the timed steps"},
                 "kernel_ms_per_step": med, "kernel_ms_min_max": spread, "kernel_ms_sum": ksum,
+                "kernel_ms_series": {k: v[:40] for k, v in series.items()},
                 "kernel_ms_basis": "HIP events on the launch stream, median over %d consecutive steps after the timed "
                                    "region (no host sync between them)" % max(20, args.steps),
             }
             line = {
                 "metric": "cross-correlations/sec (N=%d float32 pairs)" % n,
                 "value": value, "unit": "cross-correlations/s", "n_gpus": world, "steps": args.steps,
-                "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+                "warmup": args.warmup, "preconditioning_steps": pre,
+                "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
                 "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                 "config": {"workload": "batched xcorr, N=%d frames/sample (source 2N), %d pairs per GPU per step, "
                                        "48 kHz mono float32, planted delays, SNR 0 dB" % (n, batch),
@@ -472,8 +561,8 @@ def run_rank(args):
             if single is not None:
                 line["single_pair"] = single
     if rank == 0:
-        if world == 1 and not args.no_cpu:
-            line["cpu_baseline"] = cpu_baseline(args.sample_len)
+        if cpu is not None:
+            line["cpu_baseline"] = cpu
         print(json.dumps(line), flush=True)
     if multi:
         dist.barrier()
@@ -486,6 +575,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--precondition", type=int, default=30,
+                    help="untimed steps before the timed region in all (the W warm-up steps included): clock ramp after idle")
     ap.add_argument("--sample-len", type=int, default=1440000)
     ap.add_argument("--batch", type=int, default=0, help="pairs per GPU per step (0 = auto)")
     ap.add_argument("--noise-shift", type=int, default=1)
@@ -505,7 +596,11 @@ def main():
         return spawn_ranks(args, sys.argv[1:])
     if args.dry_run:
         return dry_run(args)
-    return run_rank(args)
+    cpu = None
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_cpu:
+        # rank 0 at N = 1 only, and FIRST: forked worker processes and a clean machine, before any GPU call
+        cpu = cpu_baseline(args.sample_len)
+    return run_rank(args, cpu)
 
 
 if __name__ == "__main__":

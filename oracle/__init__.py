@@ -52,6 +52,12 @@ def lib():
         L.oracle_cross_correlation_faithful.argtypes = [dp, dp, ctypes.c_size_t,
                                                         ctypes.POINTER(ctypes.c_long), dp]
         L.oracle_baseline_backend.restype = ctypes.c_char_p
+        L.oracle_worker_create.restype = ctypes.c_void_p
+        L.oracle_worker_create.argtypes = [ctypes.c_size_t]
+        L.oracle_worker_run.restype = ctypes.c_int
+        L.oracle_worker_run.argtypes = [ctypes.c_void_p, dp, dp, ctypes.POINTER(ctypes.c_long), dp]
+        L.oracle_worker_destroy.restype = None
+        L.oracle_worker_destroy.argtypes = [ctypes.c_void_p]
         L.offt_rfft.restype = ctypes.c_int
         L.offt_rfft.argtypes = [ctypes.c_size_t, dp, ctypes.c_void_p]
         L.offt_irfft.restype = ctypes.c_int
@@ -116,6 +122,33 @@ def cross_correlation_faithful(source, sample):
     coef = ctypes.c_double(0.0)
     ret = lib().oracle_cross_correlation_faithful(_d(s), _d(t), t.size, ctypes.byref(lag), ctypes.byref(coef))
     return ret, lag.value, coef.value
+
+
+class Worker:
+    """an independent per-core worker (bench.py's node-throughput leg): one thread, plans and buffers kept between calls"""
+
+    def __init__(self, sample_len):
+        self.n = int(sample_len)
+        self._w = lib().oracle_worker_create(self.n)
+        if not self._w:
+            raise MemoryError("oracle_worker_create(%d)" % self.n)
+
+    def run(self, source, sample):
+        s = np.ascontiguousarray(source, dtype=np.float64)
+        t = np.ascontiguousarray(sample, dtype=np.float64)
+        assert t.size == self.n and s.size == 2 * self.n
+        lag = ctypes.c_long(0)
+        coef = ctypes.c_double(0.0)
+        ret = lib().oracle_worker_run(self._w, _d(s), _d(t), ctypes.byref(lag), ctypes.byref(coef))
+        return ret, lag.value, coef.value
+
+    def close(self):
+        if self._w:
+            lib().oracle_worker_destroy(self._w)
+            self._w = None
+
+    def __del__(self):
+        self.close()
 
 
 def synth_pair(seed, pair, n, noise_shift=1):

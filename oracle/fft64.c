@@ -226,19 +226,29 @@ static void stockham(const offt_plan *p, ocpx *a, ocpx *b)
     if (res != a) memcpy(a, res, sizeof(ocpx) * p->n);
 }
 
+/* smooth lengths only (no Bluestein): the same transform with the caller's scratch of n elements, for workers
+ * that keep their buffers between calls (bench.py's node-throughput leg) */
+int offt_execute_ws(const offt_plan *p, const ocpx *in, ocpx *out, int sign, ocpx *scratch)
+{
+    const size_t n = p->n;
+    if (p->bm != 0) return -1;
+    for (size_t j = 0; j < n; j++) {
+        out[j].re = in[j].re;
+        out[j].im = sign > 0 ? -in[j].im : in[j].im;
+    }
+    stockham(p, out, scratch);
+    if (sign > 0)
+        for (size_t j = 0; j < n; j++) out[j].im = -out[j].im;
+    return 0;
+}
+
 void offt_execute(const offt_plan *p, const ocpx *in, ocpx *out, int sign)
 {
     const size_t n = p->n;
     /* inverse = conj(forward(conj(.))) */
     if (p->bm == 0) {
         ocpx *scratch = malloc(sizeof(ocpx) * n);
-        for (size_t j = 0; j < n; j++) {
-            out[j].re = in[j].re;
-            out[j].im = sign > 0 ? -in[j].im : in[j].im;
-        }
-        stockham(p, out, scratch);
-        if (sign > 0)
-            for (size_t j = 0; j < n; j++) out[j].im = -out[j].im;
+        (void)offt_execute_ws(p, in, out, sign, scratch);
         free(scratch);
         return;
     }

@@ -33,6 +33,8 @@ offt_plan *offt_plan_create(size_t n);
 void offt_plan_destroy(offt_plan *p);
 /* out-of-place; in and out must not alias; `in` is preserved. */
 void offt_execute(const offt_plan *p, const ocpx *in, ocpx *out, int sign);
+/* the same with the caller's scratch of n elements; -1 for lengths that need Bluestein (use offt_execute) */
+int offt_execute_ws(const offt_plan *p, const ocpx *in, ocpx *out, int sign, ocpx *scratch);
 
 /* real transforms with FFTW r2c / c2r conventions (see header comment).
  * L >= 1.  rfft writes L/2+1 bins.  irfft reads L/2+1 bins, writes L reals. */

@@ -51,6 +51,13 @@ int oracle_cross_correlation_f32(const float *source, const float *sample, size_
 int oracle_cross_correlation_faithful(const double *source, const double *sample, size_t sample_len,
                                       long *lag, double *coefficient);
 const char *oracle_baseline_backend(void); /* "fftw3" or "port" */
+/* bench.py's node-throughput leg: an independent per-core worker with the same arithmetic and backend -- ONE thread,
+ * plans and buffers made once (oracle_worker_create) and kept between calls; oracle_worker_run returns what the
+ * reference's call would (0, or -1 for a NaN coefficient; -2 on an internal failure). */
+typedef struct oracle_worker oracle_worker;
+oracle_worker *oracle_worker_create(size_t sample_len);
+int oracle_worker_run(oracle_worker *w, const double *source, const double *sample, long *lag, double *coefficient);
+void oracle_worker_destroy(oracle_worker *w);
 
 /* Deterministic synthetic pair generator, integer-exact so the
  * HIP generator (csrc/synth.hip) reproduces it bit for bit:
