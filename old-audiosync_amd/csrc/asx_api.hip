@@ -113,6 +113,8 @@ struct asx_plan {
         uint32_t *refine_idx = nullptr, *cand_n = nullptr, *refine_n = nullptr;
         double *refine_val = nullptr;
         unsigned long long *overflows = nullptr;
+        float *src_dc = nullptr;     // the pair's source minus its mean (float32, 2N)
+        double *stats = nullptr;     // {mean of source, sum of sample, their product = the shift of r}
         size_t cap = 0;
     } big;
     std::vector<uint32_t> h_cand_n;
@@ -524,10 +526,16 @@ static int run_group(asx_plan *p, const float *d_src, const float *d_smp, const 
 // needs the host to look at the group's counters, so only the synchronous entry points call it
 // (cross_correlation(double*), the host-array batch, the growing-window stream); the device-resident
 // asynchronous batch counts such pairs instead (asx_plan_peak_overflows).
+// Before that, the transforms of the pair are run again on (source - mean of source): an offset of hundreds of standard
+// deviations in BOTH tracks is what makes every lag a near-tie (the float32 error bound scales with both norms), and
+// r[k] = r'[k] + mean * sum(sample) exactly, a constant that k_inv_cols adds back when it forms the keys
+// (AsxPeakWs::shift, peak_key_shifted).  With the offset gone from the source's norm the window shrinks by the ratio
+// offset / deviation and the list that reaches the exact re-evaluation is short again.
 template <typename TIn>
-static int repair_overflows(asx_plan *p, int lane, size_t g, const TIn *p_src, const TIn *p_smp,
-                            int64_t *d_lag, double *d_coef, int32_t *d_ret, hipStream_t s)
+static int repair_overflows(asx_plan *p, int lane, size_t g, const float *f_src, const float *f_smp, const TIn *p_src,
+                            const TIn *p_smp, int64_t *d_lag, double *d_coef, int32_t *d_ret, hipStream_t s)
 {
+    (void)f_src;
     const AsxDev &P = p->dev;
     asx_plan::Lane &W = p->lanes[lane];
     const size_t N = p->host.N;
@@ -541,7 +549,8 @@ static int repair_overflows(asx_plan *p, int lane, size_t g, const TIn *p_src, c
         if (!B.cand) {
             B.cap = 2 * N;
             if (dev_alloc(p, &B.cand, B.cap) || dev_alloc(p, &B.refine_idx, B.cap) || dev_alloc(p, &B.refine_val, B.cap) ||
-                dev_alloc(p, &B.cand_n, 1) || dev_alloc(p, &B.refine_n, 1) || dev_alloc(p, &B.overflows, 1))
+                dev_alloc(p, &B.cand_n, 1) || dev_alloc(p, &B.refine_n, 1) || dev_alloc(p, &B.overflows, 1) ||
+                dev_alloc(p, &B.src_dc, 2 * N) || dev_alloc(p, &B.stats, 3))
                 return -1;
             HIP_TRY(hipMemsetAsync(B.overflows, 0, sizeof(unsigned long long), s));
         }
@@ -554,6 +563,15 @@ static int repair_overflows(asx_plan *p, int lane, size_t g, const TIn *p_src, c
         K.overflows = B.overflows;
         K.cap = (uint32_t)B.cap;
         HIP_TRY(hipMemsetAsync(B.cand_n, 0, sizeof(uint32_t), s));
+        // the pair's transforms again, on the source minus its mean (k_rows recomputes the bound from the new norms
+        // and zeroes the pair's running maximum and count); r = r' + stats[2]
+        if (sizeof(TIn) == sizeof(float))
+            asx_launch_dc_remove_f32((const float *)p_src + i * 2 * N, (const float *)p_smp + i * N, P.N, B.stats, B.src_dc, s);
+        else
+            asx_launch_dc_remove_f64((const double *)p_src + i * 2 * N, (const double *)p_smp + i * N, P.N, B.stats, B.src_dc, s);
+        K.shift = B.stats + 2;
+        asx_launch_fwd_cols(P, B.src_dc, f_smp + i * N, W.zxa + i * (size_t)P.M, W.zya + i * (size_t)P.M, K, 1, s);
+        asx_launch_rows(P, W.zxa + i * (size_t)P.M, W.zya + i * (size_t)P.M, W.ga + i * (size_t)P.M, K, 1, s);
         asx_launch_inv_cols(P, W.ga + i * (size_t)P.M, K, nullptr, 1, s);
         asx_launch_finalize(P, K, W.seg + i, 1, s);
         if (sizeof(TIn) == sizeof(float))
@@ -605,8 +623,9 @@ extern "C" int asx_xcorr_batch_f32_dev(asx_plan *p, const float *d_source, const
         // asx_plan_set_exact: look at the group's counters (one host synchronisation per group) and take the
         // second look at pairs whose near-tie list overflowed, before the next group reuses the workspaces
         if (p->exact_async &&
-            repair_overflows<float>(p, lane, g, d_source + done * 2 * N, d_sample + done * N, d_lag ? d_lag + done : nullptr,
-                                    d_coef + done, d_ret ? d_ret + done : nullptr, ls))
+            repair_overflows<float>(p, lane, g, d_source + done * 2 * N, d_sample + done * N, d_source + done * 2 * N,
+                                    d_sample + done * N, d_lag ? d_lag + done : nullptr, d_coef + done,
+                                    d_ret ? d_ret + done : nullptr, ls))
             return -1;
     }
     if (overlap) {
@@ -662,7 +681,7 @@ extern "C" int asx_xcorr_batch_f32(asx_plan *p, const float *source, const float
         if (run_group<float>(p, p->st_src, p->st_smp, p->st_src, p->st_smp, g, p->st_lag, p->st_coef,
                              p->st_ret, nullptr, s, 0))
             return -1;
-        if (repair_overflows<float>(p, 0, g, p->st_src, p->st_smp, p->st_lag, p->st_coef, p->st_ret, s)) return -1;
+        if (repair_overflows<float>(p, 0, g, p->st_src, p->st_smp, p->st_src, p->st_smp, p->st_lag, p->st_coef, p->st_ret, s)) return -1;
         HIP_TRY(hipMemcpyAsync(lag + done, p->st_lag, g * sizeof(int64_t), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipMemcpyAsync(coef + done, p->st_coef, g * sizeof(double), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipMemcpyAsync(ret + done, p->st_ret, g * sizeof(int32_t), hipMemcpyDeviceToHost, s));
@@ -725,7 +744,7 @@ extern "C" int asx_xcorr_f64(asx_plan *p, const double *source, const double *sa
     if (run_group<double>(p, p->st_src, p->st_smp, p->st_src64, p->st_smp64, 1, p->st_lag, p->st_coef,
                           p->st_ret, nullptr, s, 0))
         return -1;
-    if (repair_overflows<double>(p, 0, 1, p->st_src64, p->st_smp64, p->st_lag, p->st_coef, p->st_ret, s)) return -1;
+    if (repair_overflows<double>(p, 0, 1, p->st_src, p->st_smp, p->st_src64, p->st_smp64, p->st_lag, p->st_coef, p->st_ret, s)) return -1;
     int64_t h_lag = 0;
     double h_coef = 0;
     int32_t h_ret = -1;
@@ -920,7 +939,7 @@ extern "C" int asx_stream_xcorr(asx_stream *st, size_t sample_len, long *lag, do
     if (run_group<double>(p, st->src32, st->smp32, st->src64, st->smp64, 1, st->d_lag, st->d_coef, st->d_ret,
                           nullptr, s, 0))
         return -1;
-    if (repair_overflows<double>(p, 0, 1, st->src64, st->smp64, st->d_lag, st->d_coef, st->d_ret, s)) return -1;
+    if (repair_overflows<double>(p, 0, 1, st->src32, st->smp32, st->src64, st->smp64, st->d_lag, st->d_coef, st->d_ret, s)) return -1;
     int64_t h_lag = 0;
     double h_coef = 0;
     int32_t h_ret = -1;

@@ -698,6 +698,16 @@ __device__ __forceinline__ float peak_key_of(float value, uint32_t idx)
     const float z = (value != value) ? INFINITY : (value + 0.0f); // -0.0 -> +0.0 so it ties with |0|
     return idx == 0u ? z : a;
 }
+// The same when the transforms ran on (source - mean) (second look at a pair with a large offset in both tracks,
+// repair_overflows): r[k] = value + c with c = mean * sum(sample), the same for every k.  Keys are taken RELATIVE to
+// |c| -- key' = |r| - |c|, lag 0: r - |c| -- so that float32 keeps the differences between lags when |c| >> |value|;
+// a common shift changes neither the order of the keys nor the width of the near-maximum window.
+__device__ __forceinline__ float peak_key_shifted(float value, uint32_t idx, double c)
+{
+    if (value != value) return idx == 0u ? INFINITY : value;
+    const double r = (double)value + c;
+    return (float)((idx == 0u ? r : fabs(r)) - fabs(c)) + 0.0f;
+}
 __device__ __forceinline__ asx_peak_t peak_pack_key(float key, uint32_t idx)
 {
     if (key != key) key = -INFINITY;
@@ -802,6 +812,7 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_inv_cols(const AsxDe
     // maximum 0 inside a window of width 0, the lists would overflow and the synchronous entry points would
     // re-evaluate all of them exactly (seconds at N = 1 440 000).  Block-uniform; r_out (tests) still wants zeros.
     if (W.bound2[pair] == 0.f && r_out == nullptr) return;
+    const double shift = W.shift ? W.shift[pair] : 0.0; // block-uniform; non-zero only in the second look (repair_overflows)
     const int logH = logT - 1, H = T >> 1, M2 = P.M2;
     const int c0 = tile * T;
 #ifdef ASX_EXP_PAIRMOD
@@ -897,7 +908,7 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_inv_cols(const AsxDe
         // Run-time schedules (lengths outside the reference's six): r lies in LDS and is scanned there.  The
         // scan from the last stage's registers below, instantiated inside the switch over eleven radix bodies,
         // pushed these kernels into scratch (k_inv_cols 0.77 ms against 0.43 ms for the compiled-in schedule).
-        const bool fastg = even && (c0 + T <= M2) && (P.nout == P.F) && (tile != 0) && (r_out == nullptr);
+        const bool fastg = even && (c0 + T <= M2) && (P.nout == P.F) && (tile != 0) && (r_out == nullptr) && shift == 0.0;
         auto examine_slot = [&](int e, float4 g, float thr) {
             const int cg = e & (H - 1), j1 = e >> logH;
             const int j2 = c0 + 2 * cg;
@@ -908,7 +919,7 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_inv_cols(const AsxDe
             for (int h = 0; h < 4; h++) {
                 const uint32_t idx = i0 + h;
                 if (idx < P.nout && j2 + (h >> 1) < M2) {
-                    const float key = peak_key_of(val[h], idx);
+                    const float key = shift == 0.0 ? peak_key_of(val[h], idx) : peak_key_shifted(val[h], idx, shift);
                     if (key >= thr) cand_append(W, pair, idx, key);
                 }
             }
@@ -972,7 +983,7 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_inv_cols(const AsxDe
                     for (int h = 0; h < 4; h++) {
                         const uint32_t idx = i0 + h;
                         if (idx < P.nout && j2 + (h >> 1) < M2) {
-                            const float key = peak_key_of(val[h], idx);
+                            const float key = shift == 0.0 ? peak_key_of(val[h], idx) : peak_key_shifted(val[h], idx, shift);
                             if (key > best_key || (key == best_key && idx < best_idx) || best_idx == 0xFFFFFFFFu) { best_key = key; best_idx = idx; }
                             if (r_out) r_out[pair * (size_t)P.nout + idx] = val[h];
                         }
@@ -997,7 +1008,7 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_inv_cols(const AsxDe
     // Peak search (src/cross_correlation.c:52-67): largest key, smallest lag among equal keys.
     // Fast path (block-uniform): the tile is full, every lag counts, lag 0 (the signed one) is
     // not in it and r is not being dumped -> one packed maximum per slot, indices resolved at the end.
-    const bool fast = even && (c0 + T <= M2) && (P.nout == P.F) && (tile != 0) && (r_out == nullptr);
+    const bool fast = even && (c0 + T <= M2) && (P.nout == P.F) && (tile != 0) && (r_out == nullptr) && shift == 0.0;
     // second look (rare, one instantiation for both paths): the thread runs its last stage again and
     // appends every valid lag whose key is inside the window
     auto examine_again = [&](float thr) __attribute__((always_inline)) {
@@ -1012,7 +1023,7 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_inv_cols(const AsxDe
                 for (int h = 0; h < 4; h++) {
                     const uint32_t idx = i0 + h;
                     if (idx < P.nout && j2 + (h >> 1) < M2) {
-                        const float key = peak_key_of(val[h], idx);
+                        const float key = shift == 0.0 ? peak_key_of(val[h], idx) : peak_key_shifted(val[h], idx, shift);
                         if (key >= thr) cand_append(W, pair, idx, key);
                     }
                 }
@@ -1087,7 +1098,7 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_inv_cols(const AsxDe
                 for (int h = 0; h < 4; h++) {
                     const uint32_t idx = i0 + h;
                     if (idx < P.nout && j2 + (h >> 1) < M2) {
-                        const float key = peak_key_of(val[h], idx);
+                        const float key = shift == 0.0 ? peak_key_of(val[h], idx) : peak_key_shifted(val[h], idx, shift);
                         if (key > best_key || (key == best_key && idx < best_idx) || best_idx == 0xFFFFFFFFu) { best_key = key; best_idx = idx; }
                         if (r_out) r_out[pair * (size_t)P.nout + idx] = val[h];
                     }
@@ -1437,6 +1448,39 @@ __global__ __launch_bounds__(ASX_THREADS) void k_results_to_ms(const int64_t *__
 }
 
 // ---------------------------------------------------------------------------
+// second look, DC removal (repair_overflows): one pair, one block each.  An offset of hundreds of standard deviations
+// in BOTH tracks makes the float32 error bound (proportional to |source|_2 |sample|_2) wider than the whole range of
+// r, every lag a near-tie.  r'[k] = sum (source[n+k] - m) sample[n] = r[k] - m * sum(sample) for ANY constant m: the
+// transforms then run on a zero-mean source, whose norm no longer carries the offset, and the constant goes back in
+// when the keys are formed (peak_key_shifted).  The reference needs none of this: float64 (src/cross_correlation.c:34).
+// ---------------------------------------------------------------------------
+template <typename TIn>
+__global__ __launch_bounds__(1024) void k_dc_stats(const TIn *__restrict__ src, const TIn *__restrict__ smp, uint32_t N,
+                                                    double *__restrict__ stats)
+{
+    __shared__ double red[2][16];
+    double a = 0.0, b = 0.0;
+    for (uint32_t i = threadIdx.x; i < 2u * N; i += 1024u) a += (double)src[i];
+    for (uint32_t i = threadIdx.x; i < N; i += 1024u) b += (double)smp[i];
+    a = wave_sum(a); b = wave_sum(b);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a; red[1][threadIdx.x >> 6] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; w++) { a += red[0][w]; b += red[1][w]; }
+        const double mean = a / (2.0 * (double)N);
+        stats[0] = mean; stats[1] = b; stats[2] = mean * b;
+    }
+}
+template <typename TIn>
+__global__ __launch_bounds__(ASX_THREADS) void k_dc_apply(const TIn *__restrict__ src, uint32_t N, const double *__restrict__ stats,
+                                                           float *__restrict__ out)
+{
+    const double mean = stats[0];
+    for (size_t i = (size_t)blockIdx.x * ASX_THREADS + threadIdx.x; i < 2 * (size_t)N; i += (size_t)gridDim.x * ASX_THREADS)
+        out[i] = (float)((double)src[i] - mean);
+}
+
+// ---------------------------------------------------------------------------
 // double -> float conversion of the reference's f64 buffers
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(ASX_THREADS) void k_cvt_f64_f32(const double *__restrict__ in,
@@ -1774,6 +1818,17 @@ void asx_launch_cvt_f64_f32(const double *in, float *out, size_t n, hipStream_t 
     if (blocks > 2048) blocks = 2048;
     if (blocks == 0) blocks = 1;
     hipLaunchKernelGGL(k_cvt_f64_f32, dim3((unsigned)blocks), dim3(ASX_THREADS), 0, s, in, out, n);
+}
+
+void asx_launch_dc_remove_f32(const float *src, const float *smp, uint32_t N, double *stats, float *out, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_dc_stats<float>, dim3(1), dim3(1024), 0, s, src, smp, N, stats);
+    hipLaunchKernelGGL(k_dc_apply<float>, dim3(512), dim3(ASX_THREADS), 0, s, src, N, stats, out);
+}
+void asx_launch_dc_remove_f64(const double *src, const double *smp, uint32_t N, double *stats, float *out, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_dc_stats<double>, dim3(1), dim3(1024), 0, s, src, smp, N, stats);
+    hipLaunchKernelGGL(k_dc_apply<double>, dim3(512), dim3(ASX_THREADS), 0, s, src, N, stats, out);
 }
 
 void asx_launch_synth(uint64_t seed, uint64_t first_pair, size_t count, uint32_t N, int noise_shift,

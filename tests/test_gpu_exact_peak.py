@@ -116,6 +116,25 @@ def test_float32_error_stays_inside_the_bound(mod, n):
     with mod.Plan(n, 1, 0) as plan:
         F = plan.fft_len
         bound_rel = 4.0 * 2.0 ** -24 * np.log2(F)
+        # Spectra that put all their energy where an error of the transforms would not average out:
+        # a single bin that is a multiple of the four-step factor M1 (one column of the [M1][M2] matrix carries
+        # everything), the Nyquist bin, and impulse trains of period M2 and 2*M1 (time-domain counterparts).
+        m1, m2, _ = plan.split
+        i2 = np.arange(2 * n, dtype=np.float64)
+        rng = np.random.default_rng(3)
+
+        def pair_from(sig):
+            src_ = sig.astype(np.float32)
+            smp_ = (np.roll(sig, -37)[:n] * 0.5).astype(np.float32)
+            return src_, smp_
+        if F == 2 * n and n >= 1000:
+            cases["bin k = M1 (stride of the four-step split)"] = pair_from(np.cos(2 * np.pi * m1 * i2 / (2 * n)) + 1e-3 * rng.normal(size=2 * n))
+            cases["bin k = 3*M2 + 1"] = pair_from(np.cos(2 * np.pi * (3 * m2 + 1) * i2 / (2 * n) + 0.3))
+            cases["Nyquist"] = pair_from(np.where(np.arange(2 * n) % 2 == 0, 1.0, -1.0) + 1e-3 * rng.normal(size=2 * n))
+            imp = np.zeros(2 * n); imp[:: 2 * m2] = 1.0
+            cases["impulse train, period 2*M2 samples"] = pair_from(imp + 1e-4 * rng.normal(size=2 * n))
+            imp = np.zeros(2 * n); imp[5:: 2 * m1] = 1.0
+            cases["impulse train, period 2*M1 samples"] = pair_from(imp + 1e-4 * rng.normal(size=2 * n))
         for name, (src, smp) in cases.items():
             o_ret, o_lag, o_coef, o_r, margin = oracle.cross_correlation(src, smp, want_results=True)
             d_src = torch.from_numpy(src).cuda()
@@ -221,8 +240,8 @@ def test_pearson_large_offsets_direct(hostlib):
 
 def test_pearson_large_source_offset_through_cross_correlation(hostlib):
     """cross_correlation(double*) runs the Pearson reduction on the caller's doubles.  The source carries a
-    DC offset of 1e3..3e4 x its amplitude, the sample none (a DC term in BOTH tracks swamps float32 transforms
-    and is outside what the path resolves -- see DESIGN.md); lag and coefficient must match the oracle."""
+    DC offset of 1e3..3e4 x its amplitude, the sample none (both tracks offset: the next test); lag and
+    coefficient must match the oracle."""
     rng = np.random.default_rng(7)
     for trial in range(8):
         n = int(rng.choice([6000, 48000, 144000]))
@@ -239,3 +258,41 @@ def test_pearson_large_source_offset_through_cross_correlation(hostlib):
         assert margin > 1.0 + 1e-9
         assert (ret, lag) == (o_ret, o_lag) == (0, d), (trial, n, off, amp, lag, o_lag, d)
         assert abs(coef - o_coef) < COEF_TOL, (trial, n, off, amp, coef, o_coef)
+
+
+@pytest.mark.parametrize("n", [6000, 144000])
+def test_offset_in_both_tracks_takes_the_mean_removed_second_look(mod, hostlib, n):
+    """An offset of 1e2 .. 1e4 standard deviations in BOTH tracks: the float32 error bound scales with both norms, so
+    every lag is a near-tie of the float32 maximum and the lists overflow.  The synchronous entry points then run the
+    pair's transforms again on (source - its mean) and add mean * sum(sample) back when the keys are formed
+    (repair_overflows, peak_key_shifted): the list that reaches the exact re-evaluation is short again and the answer is
+    the oracle's, in milliseconds instead of seconds.  The reference handles it because it is float64 end to end
+    (src/cross_correlation.c:34,237).  DESIGN.md section 1, numeric contract."""
+    import time
+    rng = np.random.default_rng(41)
+    for k, ratio in enumerate([1e2, 1e3, 1e4, -1e3]):
+        d = int(rng.integers(-n // 2, n // 2))
+        x = rng.normal(size=3 * n)
+        src = ratio + x[n: 3 * n]
+        smp = abs(ratio) * 0.7 + 0.5 * x[n + d: 2 * n + d] + 0.3 * rng.normal(size=n)
+        src32, smp32 = src.astype(np.float32), smp.astype(np.float32)
+        s64, t64 = src32.astype(np.float64), smp32.astype(np.float64)
+        o_ret, o_lag, o_coef, o_r, margin = oracle.cross_correlation(s64, t64, want_results=True)
+        # (the planted delay need not win: the sample's offset times the window sums of the source is part of r too;
+        #  what counts is the float64 answer; with r = r' + mean * sum(sample) the ratio of the two largest |r| is
+        #  1 + O(r' / c): still 1e5 float64 roundings apart)
+        assert o_ret == 0 and margin > 1.0 + 1e-11
+        d = o_lag
+        # the reference's API (doubles)
+        call_cross_correlation(hostlib, s64, t64)
+        t0 = time.perf_counter()
+        ret, lag, coef = call_cross_correlation(hostlib, s64, t64)
+        dt = time.perf_counter() - t0
+        assert (ret, lag) == (0, d) and abs(coef - o_coef) < COEF_TOL, (ratio, lag, d, coef, o_coef)
+        assert dt < 0.5, (ratio, dt)
+        # the batched float32 entry points: host arrays (synchronous) and device-resident with asx_plan_set_exact
+        with mod.Plan(n, 1, 0) as plan:
+            lag_b, coef_b, ret_b = plan.xcorr_batch_f32(src32[None], smp32[None])
+            assert (int(ret_b[0]), int(lag_b[0])) == (0, d) and abs(float(coef_b[0]) - o_coef) < COEF_TOL
+            if n > 6000 or plan.peak_capacity < 2 * n:
+                assert plan.peak_repairs() >= (1 if abs(ratio) >= 1e3 else 0)
