@@ -97,7 +97,8 @@ extern int audiosync_run(const char *yt_title, long int *lag);
  * source has 2*30*SAMPLE_RATE doubles worth of capacity, sample 30*SAMPLE_RATE;
  * shorter buffers are zero-filled like src/ffmpeg_pipe.c:139-149 does.
  * frames_per_ms throttles delivery (0 = as fast as possible).  The buffers must
- * stay valid until audiosync_run() returns.  Returns 0. */
+ * stay valid until audiosync_run() returns.  Returns 0, or -1 while a run is in
+ * progress (its producers are reading the feed: call it in IDLE_ST only). */
 extern int audiosync_set_feed(const double *source, size_t source_len,
                               const double *sample, size_t sample_len,
                               unsigned frames_per_ms);
@@ -106,8 +107,9 @@ extern int audiosync_set_feed(const double *source, size_t source_len,
  * reference's producers read from their ffmpeg children (`-f f64le`, src/capture/linux_capture.c:370,
  * src/download/linux_download.c:41; chunked reads of src/ffmpeg_pipe.c:68-81).  source_path is the
  * downloaded track (up to 2*30 s are read), sample_path the recorded one (up to 30 s); a short file is
- * zero-filled.  A path that cannot be opened aborts the run like a failed ffmpeg child.  Returns 0, or
- * -1 for a NULL path. */
+ * zero-filled.  A path that cannot be opened aborts the run like a failed ffmpeg child; a FIFO whose writer
+ * has not started, or stalls, is waited for with the status checked every 100 ms, so audiosync_abort() ends
+ * the run.  Returns 0, or -1 for a NULL path or while a run is in progress. */
 extern int audiosync_set_feed_files(const char *source_path, const char *sample_path);
 
 /* Debug aid replacing the reference's compile-time PLOT/gnuplot dumps

@@ -129,10 +129,10 @@ struct asx_plan {
 
     // Profiling: HIP events around every kernel family, on the stream the kernels run on.  A ring of
     // the last `prof_depth` batch calls is kept so that consecutive steps can be timed without a
-    // host synchronisation between them (6 events per group, the first ASX_PROF_GROUPS groups of a call).
+    // host synchronisation between them (6 events per launch group, every group of a call).
     bool profiling = false;
-    size_t prof_depth = 1, prof_calls = 0, prof_base = 0;
-    std::vector<hipEvent_t> ev;
+    size_t prof_depth = 1, prof_calls = 0, prof_ring = 0;
+    std::vector<std::vector<hipEvent_t>> evr; // ring slot -> 6 events per launch group of that call, grown as needed
     std::vector<size_t> prof_groups; // groups recorded by the call in ring slot i
     size_t ev_groups = 0;            // groups recorded by the call in progress / the latest call
 };
@@ -239,6 +239,8 @@ static int plan_init(asx_plan *p, size_t N, size_t max_batch, const char *split)
         HIP_TRY(hipMemcpy(dcopy, &d, sizeof(AsxDev), hipMemcpyHostToDevice));
     }
     HIP_TRY(hipStreamCreate(&p->stream));
+    // the tables and the memsets above went through the null stream; the lanes' streams are non-blocking
+    HIP_TRY(hipDeviceSynchronize());
     return 0;
 }
 
@@ -358,7 +360,8 @@ extern "C" void asx_plan_destroy(asx_plan *p)
         if (ln.done) (void)hipEventDestroy(ln.done);
     }
     if (p->fork) (void)hipEventDestroy(p->fork);
-    for (hipEvent_t ev : p->ev) (void)hipEventDestroy(ev);
+    for (auto &ring : p->evr)
+        for (hipEvent_t ev : ring) (void)hipEventDestroy(ev);
     for (void *a : p->allocs) (void)hipFree(a);
     (void)hipSetDevice(prev);
     delete p;
@@ -452,34 +455,34 @@ extern "C" int asx_plan_split(const asx_plan *p, int *m1, int *m2, int *tile_col
 // ---------------------------------------------------------------------------
 // running groups
 // ---------------------------------------------------------------------------
-#define ASX_PROF_GROUPS 16
 static void prof_begin_call(asx_plan *p)
 {
     p->ev_groups = 0;
     if (!p->profiling) return;
-    const size_t ring = p->prof_calls % p->prof_depth;
-    p->prof_base = ring * ASX_PROF_GROUPS * 6;
+    p->prof_ring = p->prof_calls % p->prof_depth;
     if (p->prof_groups.size() < p->prof_depth) p->prof_groups.resize(p->prof_depth, 0);
-    p->prof_groups[ring] = 0;
+    if (p->evr.size() < p->prof_depth) p->evr.resize(p->prof_depth);
+    p->prof_groups[p->prof_ring] = 0;
 }
 static void prof_end_call(asx_plan *p, size_t groups)
 {
     if (!p->profiling) return;
-    p->ev_groups = std::min<size_t>(groups, ASX_PROF_GROUPS);
-    p->prof_groups[p->prof_calls % p->prof_depth] = p->ev_groups;
+    p->ev_groups = groups;
+    p->prof_groups[p->prof_ring] = groups;
     p->prof_calls++;
 }
 
+// every launch group of a call is recorded: the ring slot's event list grows with the call
 static int prof_mark(asx_plan *p, hipStream_t s, size_t slot)
 {
-    if (!p->profiling || slot >= ASX_PROF_GROUPS * 6) return 0;
-    slot += p->prof_base;
-    while (p->ev.size() <= slot) {
-        hipEvent_t ev;
-        HIP_TRY(hipEventCreate(&ev));
-        p->ev.push_back(ev);
+    if (!p->profiling) return 0;
+    std::vector<hipEvent_t> &ev = p->evr[p->prof_ring];
+    while (ev.size() <= slot) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreate(&e));
+        ev.push_back(e);
     }
-    HIP_TRY(hipEventRecord(p->ev[slot], s));
+    HIP_TRY(hipEventRecord(ev[slot], s));
     return 0;
 }
 
@@ -547,12 +550,16 @@ static int repair_overflows(asx_plan *p, int lane, size_t g, const float *f_src,
         if (p->h_cand_n[i] <= W.pk.cap) continue;
         asx_plan::BigPeak &B = p->big;
         if (!B.cand) {
-            B.cap = 2 * N;
-            if (dev_alloc(p, &B.cand, B.cap) || dev_alloc(p, &B.refine_idx, B.cap) || dev_alloc(p, &B.refine_val, B.cap) ||
-                dev_alloc(p, &B.cand_n, 1) || dev_alloc(p, &B.refine_n, 1) || dev_alloc(p, &B.overflows, 1) ||
-                dev_alloc(p, &B.src_dc, 2 * N) || dev_alloc(p, &B.stats, 3))
+            // into a local first: a failed allocation must not leave half a set behind for the next call
+            // (what was allocated stays on the plan's list and is freed with the plan)
+            asx_plan::BigPeak T;
+            T.cap = 2 * N;
+            if (dev_alloc(p, &T.cand, T.cap) || dev_alloc(p, &T.refine_idx, T.cap) || dev_alloc(p, &T.refine_val, T.cap) ||
+                dev_alloc(p, &T.cand_n, 1) || dev_alloc(p, &T.refine_n, 1) || dev_alloc(p, &T.overflows, 1) ||
+                dev_alloc(p, &T.src_dc, 2 * N) || dev_alloc(p, &T.stats, 3))
                 return -1;
-            HIP_TRY(hipMemsetAsync(B.overflows, 0, sizeof(unsigned long long), s));
+            HIP_TRY(hipMemsetAsync(T.overflows, 0, sizeof(unsigned long long), s));
+            B = T;
         }
         AsxPeakWs K = W.pk;               // the pair's own norms, bound and (final) float32 maximum ...
         K.nrm_part += i * 2 * (size_t)P.ntiles;
@@ -766,32 +773,54 @@ struct PearsonScratch {
     AsxSeg *seg = nullptr;
     hipStream_t stream = nullptr;
 };
-static PearsonScratch g_pearson[16];
+static std::mutex g_pearson_lock;
+static std::vector<PearsonScratch *> g_pearson; // by device id, created on first use, kept for the life of the process
 
 extern "C" int asx_pearson_f64(const double *a, const double *b, size_t n, int device, double *out)
 {
     if (!a || !b || !out) return fail("asx_pearson_f64: null argument");
     if (n > 0xFFFFFFFFull) return fail("asx_pearson_f64: range too long");
-    if (asx_device_count() == 0) return fail("no usable HIP device; this library has no CPU fallback");
+    const int ndev = asx_device_count();
+    if (ndev == 0) return fail("no usable HIP device; this library has no CPU fallback");
     if (device < 0) HIP_TRY(hipGetDevice(&device));
-    if (device >= 16) return fail("asx_pearson_f64: device %d not supported", device);
+    if (device >= ndev) return fail("asx_pearson_f64: device %d out of range (%d devices)", device, ndev);
     DevGuard dg(device);
     if (!dg.ok) return fail("cannot select device %d", device);
-    PearsonScratch &S = g_pearson[device];
+    PearsonScratch *Sp = nullptr;
+    {
+        std::lock_guard<std::mutex> g(g_pearson_lock);
+        if (g_pearson.size() <= (size_t)device) g_pearson.resize((size_t)device + 1, nullptr);
+        if (!g_pearson[(size_t)device]) g_pearson[(size_t)device] = new PearsonScratch();
+        Sp = g_pearson[(size_t)device];
+    }
+    PearsonScratch &S = *Sp;
     std::lock_guard<std::mutex> guard(S.lock);
     if (!S.stream) {
-        HIP_TRY(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
-        HIP_TRY(hipMalloc((void **)&S.ps, ASX_PEARSON_BLOCKS * 6 * sizeof(double)));
-        HIP_TRY(hipMalloc((void **)&S.c, sizeof(double)));
-        HIP_TRY(hipMalloc((void **)&S.seg, sizeof(AsxSeg)));
+        // committed only when every piece exists: a failed allocation leaves nothing half-initialised behind
+        hipStream_t st = nullptr;
+        double *ps = nullptr, *c = nullptr;
+        AsxSeg *seg = nullptr;
+        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess ||
+            hipMalloc((void **)&ps, ASX_PEARSON_BLOCKS * 6 * sizeof(double)) != hipSuccess ||
+            hipMalloc((void **)&c, sizeof(double)) != hipSuccess || hipMalloc((void **)&seg, sizeof(AsxSeg)) != hipSuccess) {
+            const hipError_t e = hipGetLastError();
+            if (st) (void)hipStreamDestroy(st);
+            (void)hipFree(ps); (void)hipFree(c); (void)hipFree(seg);
+            return fail("asx_pearson_f64: scratch allocation failed: %s", hipGetErrorString(e));
+        }
+        S.ps = ps; S.c = c; S.seg = seg; S.stream = st;
     }
     if (n > S.cap) {
         (void)hipFree(S.a); (void)hipFree(S.b);
         S.a = S.b = nullptr; S.cap = 0;
         const size_t want = std::max<size_t>(n, 4096);
-        HIP_TRY(hipMalloc((void **)&S.a, want * sizeof(double)));
-        HIP_TRY(hipMalloc((void **)&S.b, want * sizeof(double)));
-        S.cap = want;
+        double *na = nullptr, *nb = nullptr;
+        if (hipMalloc((void **)&na, want * sizeof(double)) != hipSuccess || hipMalloc((void **)&nb, want * sizeof(double)) != hipSuccess) {
+            const hipError_t e = hipGetLastError();
+            (void)hipFree(na); (void)hipFree(nb);
+            return fail("asx_pearson_f64: hipMalloc failed: %s", hipGetErrorString(e));
+        }
+        S.a = na; S.b = nb; S.cap = want;
     }
     AsxSeg seg{};
     seg.lag = 0; seg.src_off = 0; seg.smp_off = 0; seg.len = (uint32_t)n; seg.peak = 0;
@@ -979,6 +1008,7 @@ extern "C" int asx_plan_set_profiling(asx_plan *p, int depth)
     p->prof_depth = depth > 0 ? (size_t)depth : 1;
     p->prof_calls = 0;
     p->prof_groups.assign(p->prof_depth, 0);
+    if (p->evr.size() < p->prof_depth) p->evr.resize(p->prof_depth);
     p->ev_groups = 0;
     return 0;
 }
@@ -994,7 +1024,8 @@ extern "C" int asx_plan_timings_ms(asx_plan *p, int calls_back, float out[6])
     const size_t ring = (p->prof_calls - 1 - (size_t)calls_back) % p->prof_depth;
     const size_t groups = p->prof_groups[ring];
     if (groups == 0) return fail("no profiled call recorded");
-    const hipEvent_t *ev = p->ev.data() + ring * ASX_PROF_GROUPS * 6;
+    if (p->evr.size() <= ring || p->evr[ring].size() < groups * 6) return fail("no profiled call recorded");
+    const hipEvent_t *ev = p->evr[ring].data();
     DevGuard dg(p->device);
     for (size_t g = 0; g < groups; g++) {
         HIP_TRY(hipEventSynchronize(ev[g * 6 + 5]));

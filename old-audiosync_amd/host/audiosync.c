@@ -20,6 +20,7 @@
 #include <errno.h>
 #include <fcntl.h>
 #include <math.h>
+#include <poll.h>
 #include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -132,10 +133,15 @@ static void feed_clear(struct feed *f)
     f->data = NULL; f->len = 0; f->path = NULL;
 }
 
+/* Both setters refuse while a run is in progress (-1): the producers of that run are reading the feed. */
 int audiosync_set_feed(const double *source, size_t source_len, const double *sample,
                        size_t sample_len, unsigned frames_per_ms)
 {
     pthread_mutex_lock(&mutex);
+    if (global_status != IDLE_ST) {
+        pthread_mutex_unlock(&mutex);
+        return -1;
+    }
     feed_clear(&feed_source); feed_clear(&feed_sample);
     feed_source.data = source; feed_source.len = source_len;
     feed_sample.data = sample; feed_sample.len = sample_len;
@@ -158,6 +164,11 @@ int audiosync_set_feed_files(const char *source_path, const char *sample_path)
         return -1;
     }
     pthread_mutex_lock(&mutex);
+    if (global_status != IDLE_ST) {
+        pthread_mutex_unlock(&mutex);
+        free(a); free(b);
+        return -1;
+    }
     feed_clear(&feed_source); feed_clear(&feed_sample);
     feed_source.path = a;
     feed_sample.path = b;
@@ -172,17 +183,39 @@ struct producer_args {
     unsigned frames_per_ms;
 };
 
-/* reads up to `want` bytes; returns the bytes read (short only at end of file), -1 on error */
-static ssize_t read_fully(int fd, void *dst, size_t want)
+static int aborting(void)
+{
+    pthread_mutex_lock(&mutex);
+    const int a = (global_status == ABORT_ST);
+    pthread_mutex_unlock(&mutex);
+    return a;
+}
+
+/* Reads up to `want` bytes from a descriptor opened O_NONBLOCK; returns the bytes read (short only at end of file),
+ * -1 on error, -2 when the job was aborted while waiting.  A FIFO whose writer has not started yet, or stalls, must not
+ * hold the run hostage: poll() with a timeout, the status checked every round.  End of file = a zero-byte read while
+ * poll() reports the descriptor readable or hung up (a FIFO nobody has opened for writing yet reports neither). */
+static ssize_t read_chunk(int fd, void *dst, size_t want)
 {
     size_t got = 0;
     while (got < want) {
-        const ssize_t r = read(fd, (char *) dst + got, want - got);
-        if (r < 0) {
+        struct pollfd pf = { .fd = fd, .events = POLLIN, .revents = 0 };
+        const int pr = poll(&pf, 1, 100);
+        if (pr < 0) {
             if (errno == EINTR) continue;
             return -1;
         }
-        if (r == 0) break;
+        if (aborting()) return -2;
+        if (pr == 0) continue;
+        const ssize_t r = read(fd, (char *) dst + got, want - got);
+        if (r < 0) {
+            if (errno == EINTR || errno == EAGAIN) continue;
+            return -1;
+        }
+        if (r == 0) {
+            if (pf.revents & (POLLIN | POLLHUP)) break;
+            continue;
+        }
         got += (size_t) r;
     }
     return (ssize_t) got;
@@ -196,7 +229,7 @@ static void *producer(void *arg)
     int fd = -1;
     size_t avail = pa->in.data ? (pa->in.len < d->total_len ? pa->in.len : d->total_len) : 0;
     if (pa->in.path) {
-        fd = open(pa->in.path, O_RDONLY);
+        fd = open(pa->in.path, O_RDONLY | O_NONBLOCK); /* a FIFO without a writer yet opens at once */
         if (fd < 0) {
             /* like a failed ffmpeg child (src/ffmpeg_pipe.c:59-62): the job is aborted */
             perror("audiosync: open of the feed file failed");
@@ -210,7 +243,11 @@ static void *producer(void *arg)
         size_t step = avail - d->len < FEED_STEP ? avail - d->len : FEED_STEP;
         if (fd >= 0) {
             /* src/ffmpeg_pipe.c:68-81: one chunk of f64le frames; end of file ends the track */
-            const ssize_t got = read_fully(fd, d->buf + d->len, step * sizeof(*d->buf));
+            const ssize_t got = read_chunk(fd, d->buf + d->len, step * sizeof(*d->buf));
+            if (got == -2) { /* aborted while waiting for the writer */
+                close(fd);
+                return NULL;
+            }
             if (got < 0) {
                 perror("audiosync: read of the feed file failed");
                 close(fd);
@@ -274,6 +311,7 @@ int audiosync_run(const char *yt_title, long *lag)
         .intervals = interv_source, .n_intervals = N_INTERVALS,
     };
     struct producer_args cap_pa, down_pa;
+    int own_paths = 0;
     asx_stream *stream = NULL;
 
     if (sample == NULL || source == NULL) {
@@ -283,7 +321,15 @@ int audiosync_run(const char *yt_title, long *lag)
     pthread_mutex_lock(&mutex);
     cap_pa.out = &cap_args; cap_pa.in = feed_sample; cap_pa.frames_per_ms = feed_frames_per_ms;
     down_pa.out = &down_args; down_pa.in = feed_source; down_pa.frames_per_ms = feed_frames_per_ms;
+    /* the run keeps its own copies of the paths (the setters refuse while it is in progress, this is the belt) */
+    if (cap_pa.in.path) cap_pa.in.path = strdup(cap_pa.in.path);
+    if (down_pa.in.path) down_pa.in.path = strdup(down_pa.in.path);
     pthread_mutex_unlock(&mutex);
+    own_paths = 1;
+    if ((feed_sample.path && !cap_pa.in.path) || (feed_source.path && !down_pa.in.path)) {
+        perror("audiosync: strdup for the feed paths failed");
+        goto finish;
+    }
     if ((cap_pa.in.data == NULL && cap_pa.in.path == NULL) || (down_pa.in.data == NULL && down_pa.in.path == NULL)) {
         /* nothing to record or download: the reference's producers fail and abort the job */
         LOG("no feed configured (audiosync_set_feed / audiosync_set_feed_files); aborting");
@@ -344,6 +390,7 @@ finish:
     if (down_started) pthread_join(down_th, NULL);
     free(sample);
     free(source);
+    if (own_paths) { free(cap_pa.in.path); free(down_pa.in.path); }
     global_status = IDLE_ST;
     LOG("finished run");
     return ret;

@@ -136,17 +136,26 @@ static int as_reals(PyObject *obj, Py_buffer *view, const char *what)
 static pthread_mutex_t f32_mutex = PTHREAD_MUTEX_INITIALIZER;
 static asx_plan *f32_plan;
 static size_t f32_plan_n, f32_plan_cap;
+static int f32_plan_dev = -1;
 
 /* with the GIL released */
 static int run_f32(const float *src, const float *smp, size_t n, size_t batch, int64_t *lag, double *coef, int32_t *ret)
 {
     int rc = -1;
     pthread_mutex_lock(&f32_mutex);
-    if (!f32_plan || f32_plan_n != n || f32_plan_cap < batch) {
+    /* keyed on the sample length, the batch capacity AND the current HIP device (like the float64 path's plan cache):
+     * after torch.cuda.set_device() the call must not keep running on the old device.  The capacity grows
+     * geometrically, so a caller whose batches creep up does not rebuild the plan at every call. */
+    const int dev = asx_current_device();
+    if (!f32_plan || f32_plan_n != n || f32_plan_cap < batch || f32_plan_dev != dev) {
+        size_t cap = batch;
+        if (f32_plan && f32_plan_n == n && f32_plan_dev == dev && cap < 2 * f32_plan_cap) cap = 2 * f32_plan_cap;
         if (f32_plan) asx_plan_destroy(f32_plan);
-        f32_plan = asx_plan_create(n, batch, -1);
+        f32_plan = asx_plan_create(n, cap, dev);
+        if (!f32_plan && cap != batch) { cap = batch; f32_plan = asx_plan_create(n, cap, dev); }
         f32_plan_n = n;
-        f32_plan_cap = batch;
+        f32_plan_cap = f32_plan ? cap : 0;
+        f32_plan_dev = dev;
     }
     if (f32_plan) rc = asx_xcorr_batch_f32(f32_plan, src, smp, batch, lag, coef, ret);
     pthread_mutex_unlock(&f32_mutex);
@@ -251,12 +260,19 @@ static PyObject *mod_cross_correlation_batch(PyObject *self, PyObject *args)
     }
     PyObject *rets = PyList_New(batch), *lags = PyList_New(batch), *coefs = PyList_New(batch);
     if (rets && lags && coefs) {
-        for (Py_ssize_t b = 0; b < batch; b++) {
-            PyList_SET_ITEM(rets, b, PyLong_FromLong(ret[b]));
-            PyList_SET_ITEM(lags, b, PyLong_FromLongLong((long long)lag[b]));
-            PyList_SET_ITEM(coefs, b, PyFloat_FromDouble(coef[b]));
+        int ok = 1;
+        for (Py_ssize_t b = 0; b < batch && ok; b++) {
+            PyObject *r = PyLong_FromLong(ret[b]), *l = PyLong_FromLongLong((long long)lag[b]), *c = PyFloat_FromDouble(coef[b]);
+            if (!r || !l || !c) {
+                Py_XDECREF(r); Py_XDECREF(l); Py_XDECREF(c);
+                ok = 0;
+                break;
+            }
+            PyList_SET_ITEM(rets, b, r);
+            PyList_SET_ITEM(lags, b, l);
+            PyList_SET_ITEM(coefs, b, c);
         }
-        result = PyTuple_Pack(3, rets, lags, coefs);
+        if (ok) result = PyTuple_Pack(3, rets, lags, coefs);
     }
     Py_XDECREF(rets); Py_XDECREF(lags); Py_XDECREF(coefs);
 done:
@@ -286,7 +302,13 @@ static PyObject *mod_set_feed(PyObject *self, PyObject *args)
     }
     memcpy(s, src.buf, (size_t)src.len);
     memcpy(t, smp.buf, (size_t)smp.len);
-    audiosync_set_feed(s, (size_t)src.len / sizeof(double), t, (size_t)smp.len / sizeof(double), frames_per_ms);
+    if (audiosync_set_feed(s, (size_t)src.len / sizeof(double), t, (size_t)smp.len / sizeof(double), frames_per_ms) != 0) {
+        /* a run started between the status check above and here: the library refused */
+        free(s); free(t);
+        PyBuffer_Release(&src); PyBuffer_Release(&smp);
+        PyErr_SetString(PyExc_RuntimeError, "set_feed() while a run is in progress");
+        return NULL;
+    }
     free(feed_source_copy); free(feed_sample_copy);
     feed_source_copy = s; feed_sample_copy = t;
     PyBuffer_Release(&src); PyBuffer_Release(&smp);

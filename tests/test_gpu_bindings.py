@@ -148,3 +148,27 @@ def test_run_from_f64le_files_and_a_fifo(audiosync, tmp_path):
     audiosync.set_feed_files(str(tmp_path / "missing.f64le"), str(fsmp))
     lag_ms, ok = audiosync.run("missing")
     assert ok is False and audiosync.status() == "idle"
+
+
+def test_fifo_whose_writer_never_starts_can_be_aborted(audiosync, tmp_path):
+    """open() of a FIFO used to block until a writer appeared and read() between chunks, so abort() was
+    never seen and run() hung in pthread_join.  The producers now open O_NONBLOCK and poll() with a timeout, the status
+    checked every round (host/audiosync.c read_chunk)."""
+    rng = np.random.default_rng(6)
+    source = rng.uniform(-1, 1, 2 * 30 * 48000)
+    fsrc = tmp_path / "source.f64le"
+    source.astype("<f8").tofile(fsrc)
+    fifo = tmp_path / "nobody_writes.fifo"
+    os.mkfifo(fifo)
+    audiosync.set_feed_files(str(fsrc), str(fifo))
+    result = {}
+    th = threading.Thread(target=lambda: result.update(r=audiosync.run("stalled")))
+    th.start()
+    time.sleep(0.5)
+    assert audiosync.status() == "running"
+    with pytest.raises(RuntimeError):
+        audiosync.set_feed_files(str(fsrc), str(fsrc))      # refused while the run is in progress
+    audiosync.abort()
+    th.join(timeout=20)
+    assert not th.is_alive()
+    assert result["r"][1] is False and audiosync.status() == "idle"
