@@ -135,6 +135,31 @@ int asx_xcorr_batch_f32_dev(asx_plan *plan, const float *d_source, const float *
 int asx_xcorr_batch_multi(asx_plan *const *plans, int nplans, const float *source, const float *sample,
                           size_t batch, int64_t *lag, double *coef, int32_t *ret);
 
+/* The same with DEVICE-RESIDENT shards and the result gather done by RCCL inside the library (one
+ * host thread and one stream per device in a single process, ncclCommInitAll, one ncclAllGather per batch):
+ *
+ *   asx_shard_range(total, nshards, i, &start, &count)   block partition of a batch: the first total % nshards
+ *                       shards hold one pair more (the rule bench.py's sharding.py uses between processes)
+ *   asx_comm_create(plans, nplans)   one RCCL communicator over the plans' devices (all different, one plan each,
+ *                       all the same sample_len); librccl.so.1 is dlopen()ed here, not linked: hosts that never
+ *                       shard do not load it.  NULL on failure (asx_last_error()).
+ *   asx_xcorr_batch_multi_dev(comm, d_source, d_sample, counts, width, d_gathered)
+ *                       shard i = counts[i] <= width pairs resident on plans[i]'s device (d_source[i]: counts[i] * 2N
+ *                       floats, d_sample[i]: counts[i] * N).  Every device runs its shard on its plan's stream from
+ *                       its own host thread, then the shards' result records -- asx_result_bytes(width) bytes each:
+ *                       int64 lag[width] | double coef[width] | int32 ret[width], entries past counts[i] zero --
+ *                       are all-gathered over xGMI: d_gathered[i] (device i, nplans * asx_result_bytes(width)
+ *                       bytes) receives the record of every shard, in shard order.  Returns after all streams
+ *                       have been synchronised.  The data path itself exchanges nothing: pairs are independent.
+ *   asx_comm_destroy(comm) */
+typedef struct asx_comm asx_comm;
+int asx_shard_range(size_t total, int nshards, int shard, size_t *start, size_t *count);
+size_t asx_result_bytes(size_t width);
+asx_comm *asx_comm_create(asx_plan *const *plans, int nplans);
+void asx_comm_destroy(asx_comm *comm);
+int asx_xcorr_batch_multi_dev(asx_comm *comm, const float *const *d_source, const float *const *d_sample,
+                              const size_t *counts, size_t width, void *const *d_gathered);
+
 /* Debug/parity aid: run ONE device-resident pair and also return the raw
  * correlation r[0..2N) (device pointer, 2N floats; scaled by F/(2N) relative
  * to the reference when the length had to be embedded). */

@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -727,6 +728,173 @@ extern "C" int asx_xcorr_batch_multi(asx_plan *const *plans, int nplans, const f
     for (std::thread &t : workers) t.join();
     for (int i = 0; i < nplans; i++)
         if (rc[(size_t)i] != 0) return fail("asx_xcorr_batch_multi: plan %d: %s", i, err[(size_t)i].c_str());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// device-resident shards + RCCL result gather.  RCCL is dlopen()ed: seven entry points by name.
+// ---------------------------------------------------------------------------
+extern "C" int asx_shard_range(size_t total, int nshards, int shard, size_t *start, size_t *count)
+{
+    if (nshards < 1 || shard < 0 || shard >= nshards || !start || !count) return fail("asx_shard_range: bad argument");
+    const size_t base = total / (size_t)nshards, extra = total % (size_t)nshards;
+    *count = base + ((size_t)shard < extra ? 1 : 0);
+    *start = (size_t)shard * base + std::min((size_t)shard, extra);
+    return 0;
+}
+
+extern "C" size_t asx_result_bytes(size_t width) { return width * (sizeof(int64_t) + sizeof(double) + sizeof(int32_t)); }
+
+namespace {
+typedef void *nccl_comm_t;
+struct Rccl {
+    void *handle = nullptr;
+    int (*CommInitAll)(nccl_comm_t *, int, const int *) = nullptr;
+    int (*CommDestroy)(nccl_comm_t) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int /* ncclDataType_t */, nccl_comm_t, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    int (*GetVersion)(int *) = nullptr;
+};
+std::mutex g_rccl_lock;
+Rccl g_rccl;
+const Rccl *rccl_load()
+{
+    std::lock_guard<std::mutex> g(g_rccl_lock);
+    if (g_rccl.handle) return &g_rccl;
+    void *h = nullptr;
+    for (const char *name : { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" }) {
+        h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (h) break;
+    }
+    if (!h) { fail("cannot load librccl.so.1: %s", dlerror()); return nullptr; }
+    Rccl r;
+    r.handle = h;
+    r.CommInitAll = (int (*)(nccl_comm_t *, int, const int *))dlsym(h, "ncclCommInitAll");
+    r.CommDestroy = (int (*)(nccl_comm_t))dlsym(h, "ncclCommDestroy");
+    r.AllGather = (int (*)(const void *, void *, size_t, int, nccl_comm_t, hipStream_t))dlsym(h, "ncclAllGather");
+    r.GroupStart = (int (*)())dlsym(h, "ncclGroupStart");
+    r.GroupEnd = (int (*)())dlsym(h, "ncclGroupEnd");
+    r.GetErrorString = (const char *(*)(int))dlsym(h, "ncclGetErrorString");
+    r.GetVersion = (int (*)(int *))dlsym(h, "ncclGetVersion");
+    if (!r.CommInitAll || !r.CommDestroy || !r.AllGather || !r.GroupStart || !r.GroupEnd || !r.GetErrorString) {
+        fail("librccl.so.1 lacks an entry point this library binds");
+        dlclose(h);
+        return nullptr;
+    }
+    g_rccl = r;
+    return &g_rccl;
+}
+} // namespace
+
+struct asx_comm {
+    std::vector<asx_plan *> plans;
+    std::vector<nccl_comm_t> comms;
+    std::vector<void *> local;     // per device: the shard's result record (asx_result_bytes(width) bytes)
+    size_t width = 0;
+};
+
+extern "C" void asx_comm_destroy(asx_comm *c)
+{
+    if (!c) return;
+    const Rccl *R = g_rccl.handle ? &g_rccl : nullptr;
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    for (size_t i = 0; i < c->plans.size(); i++) {
+        (void)hipSetDevice(c->plans[i]->device);
+        if (i < c->comms.size() && c->comms[i] && R) (void)R->CommDestroy(c->comms[i]);
+        if (i < c->local.size() && c->local[i]) (void)hipFree(c->local[i]);
+    }
+    (void)hipSetDevice(prev);
+    delete c;
+}
+
+extern "C" asx_comm *asx_comm_create(asx_plan *const *plans, int nplans)
+{
+    if (!plans || nplans < 1) { fail("asx_comm_create: bad argument"); return nullptr; }
+    for (int i = 0; i < nplans; i++) {
+        if (!plans[i] || plans[i]->host.N != plans[0]->host.N) { fail("asx_comm_create: plans must share one sample_len"); return nullptr; }
+        for (int j = 0; j < i; j++)
+            if (plans[j]->device == plans[i]->device) { fail("asx_comm_create: one plan per device (device %d twice)", plans[i]->device); return nullptr; }
+    }
+    const Rccl *R = rccl_load();
+    if (!R) return nullptr;
+    asx_comm *c = new asx_comm();
+    c->plans.assign(plans, plans + nplans);
+    c->comms.assign((size_t)nplans, nullptr);
+    c->local.assign((size_t)nplans, nullptr);
+    std::vector<int> devs((size_t)nplans);
+    for (int i = 0; i < nplans; i++) devs[(size_t)i] = plans[i]->device;
+    const int rc = R->CommInitAll(c->comms.data(), nplans, devs.data());
+    if (rc != 0) {
+        fail("ncclCommInitAll over %d device(s) failed: %s", nplans, R->GetErrorString(rc));
+        c->comms.assign((size_t)nplans, nullptr);
+        asx_comm_destroy(c);
+        return nullptr;
+    }
+    return c;
+}
+
+extern "C" int asx_xcorr_batch_multi_dev(asx_comm *c, const float *const *d_source, const float *const *d_sample,
+                                         const size_t *counts, size_t width, void *const *d_gathered)
+{
+    if (!c || !d_source || !d_sample || !counts || !d_gathered || width == 0) return fail("asx_xcorr_batch_multi_dev: bad argument");
+    const Rccl *R = rccl_load();
+    if (!R) return -1;
+    const int n = (int)c->plans.size();
+    for (int i = 0; i < n; i++)
+        if (counts[i] > width || (counts[i] && (!d_source[i] || !d_sample[i])) || !d_gathered[i])
+            return fail("asx_xcorr_batch_multi_dev: shard %d: count %zu over width %zu, or a null pointer", i, counts[i], width);
+    const size_t rec = asx_result_bytes(width);
+    if (width != c->width) { // the shards' own result records, (re)sized to the width in use
+        for (int i = 0; i < n; i++) {
+            DevGuard dg(c->plans[(size_t)i]->device);
+            if (!dg.ok) return fail("cannot select device %d", c->plans[(size_t)i]->device);
+            if (c->local[(size_t)i]) { (void)hipFree(c->local[(size_t)i]); c->local[(size_t)i] = nullptr; }
+            HIP_TRY(hipMalloc(&c->local[(size_t)i], rec));
+        }
+        c->width = width;
+    }
+    std::vector<int> rc((size_t)n, 0);
+    std::vector<std::string> err((size_t)n);
+    // phase 1: every device its shard, from its own host thread, on its plan's stream (asynchronous)
+    {
+        std::vector<std::thread> workers;
+        for (int i = 0; i < n; i++) {
+            workers.emplace_back([=, &rc, &err]() {
+                asx_plan *p = c->plans[(size_t)i];
+                if (hipSetDevice(p->device) != hipSuccess) { rc[(size_t)i] = -1; err[(size_t)i] = "hipSetDevice failed"; return; }
+                char *base = (char *)c->local[(size_t)i];
+                int64_t *lag = (int64_t *)base;
+                double *coef = (double *)(base + width * sizeof(int64_t));
+                int32_t *ret = (int32_t *)(base + width * (sizeof(int64_t) + sizeof(double)));
+                if (hipMemsetAsync(base, 0, rec, p->stream) != hipSuccess) { rc[(size_t)i] = -1; err[(size_t)i] = "hipMemsetAsync failed"; return; }
+                if (counts[i]) {
+                    rc[(size_t)i] = asx_xcorr_batch_f32_dev(p, d_source[i], d_sample[i], counts[i], lag, coef, ret, p->stream);
+                    if (rc[(size_t)i] != 0) err[(size_t)i] = asx_last_error();
+                }
+            });
+        }
+        for (std::thread &t : workers) t.join();
+    }
+    for (int i = 0; i < n; i++)
+        if (rc[(size_t)i] != 0) return fail("asx_xcorr_batch_multi_dev: shard %d: %s", i, err[(size_t)i].c_str());
+    // phase 2: ONE all-gather of the records, enqueued behind the kernels on the same streams (a group call: one thread
+    // drives every rank of the in-process communicator)
+    int grc = R->GroupStart();
+    for (int i = 0; i < n && grc == 0; i++) {
+        asx_plan *p = c->plans[(size_t)i];
+        DevGuard dg(p->device);
+        grc = R->AllGather(c->local[(size_t)i], d_gathered[i], rec, 0 /* ncclInt8 / ncclChar */, c->comms[(size_t)i], p->stream);
+    }
+    const int erc = R->GroupEnd();
+    if (grc == 0) grc = erc;
+    if (grc != 0) return fail("ncclAllGather of the result records failed: %s", R->GetErrorString(grc));
+    for (int i = 0; i < n; i++) {
+        DevGuard dg(c->plans[(size_t)i]->device);
+        HIP_TRY(hipStreamSynchronize(c->plans[(size_t)i]->stream));
+    }
     return 0;
 }
 

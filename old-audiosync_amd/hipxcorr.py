@@ -25,6 +25,7 @@ ABI_SYMBOLS = [
     "asx_plan_last_timings_ms", "asx_device_malloc", "asx_device_free", "asx_memcpy_h2d",
     "asx_memcpy_d2h", "asx_stream_sync", "asx_plan_peak_overflows", "asx_plan_peak_repairs", "asx_plan_set_exact", "asx_plan_peak_capacity",
     "asx_current_device", "asx_plan_timings_ms", "asx_xcorr_batch_multi",
+    "asx_shard_range", "asx_result_bytes", "asx_comm_create", "asx_comm_destroy", "asx_xcorr_batch_multi_dev",
 ]
 
 
@@ -88,6 +89,18 @@ def lib():
     L.asx_xcorr_batch_multi.argtypes = [ctypes.POINTER(vp), ctypes.c_int, c_f32p, c_f32p, ctypes.c_size_t, c_i64p, c_f64p, c_i32p]
     L.asx_xcorr_batch_f32_dev.restype = ctypes.c_int
     L.asx_xcorr_batch_f32_dev.argtypes = [vp, vp, vp, ctypes.c_size_t, vp, vp, vp, vp]
+    L.asx_shard_range.restype = ctypes.c_int
+    L.asx_shard_range.argtypes = [ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_size_t),
+                                  ctypes.POINTER(ctypes.c_size_t)]
+    L.asx_result_bytes.restype = ctypes.c_size_t
+    L.asx_result_bytes.argtypes = [ctypes.c_size_t]
+    L.asx_comm_create.restype = vp
+    L.asx_comm_create.argtypes = [ctypes.POINTER(vp), ctypes.c_int]
+    L.asx_comm_destroy.restype = None
+    L.asx_comm_destroy.argtypes = [vp]
+    L.asx_xcorr_batch_multi_dev.restype = ctypes.c_int
+    L.asx_xcorr_batch_multi_dev.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_size_t),
+                                            ctypes.c_size_t, ctypes.POINTER(vp)]
     L.asx_xcorr_debug_r_dev.restype = ctypes.c_int
     L.asx_xcorr_debug_r_dev.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
     L.asx_pearson_f64.restype = ctypes.c_int
@@ -242,6 +255,51 @@ def xcorr_batch_multi(plans, source, sample):
     if rc != 0:
         raise AsxError(_err())
     return lag, coef, ret
+
+
+def shard_range(total, nshards, shard):
+    """block partition of a batch over shards (asx_shard_range): -> (start, count)"""
+    start, count = ctypes.c_size_t(0), ctypes.c_size_t(0)
+    if lib().asx_shard_range(total, nshards, shard, ctypes.byref(start), ctypes.byref(count)) != 0:
+        raise AsxError(_err())
+    return start.value, count.value
+
+
+def result_bytes(width):
+    return int(lib().asx_result_bytes(width))
+
+
+class Comm:
+    """One RCCL communicator over the devices of `plans` (one plan per device), created inside the library
+    (ncclCommInitAll); `run` = asx_xcorr_batch_multi_dev: device-resident shards, one all-gather of the result records."""
+
+    def __init__(self, plans):
+        self.plans = list(plans)
+        handles = (ctypes.c_void_p * len(self.plans))(*[p._h for p in self.plans])
+        self._h = lib().asx_comm_create(handles, len(self.plans))
+        if not self._h:
+            raise AsxError(_err())
+
+    def run(self, d_sources, d_samples, counts, width, d_gathered):
+        n = len(self.plans)
+        assert len(d_sources) == len(d_samples) == len(counts) == len(d_gathered) == n
+        src = (ctypes.c_void_p * n)(*d_sources)
+        smp = (ctypes.c_void_p * n)(*d_samples)
+        out = (ctypes.c_void_p * n)(*d_gathered)
+        cnt = (ctypes.c_size_t * n)(*counts)
+        if lib().asx_xcorr_batch_multi_dev(self._h, src, smp, cnt, width, out) != 0:
+            raise AsxError(_err())
+
+    def close(self):
+        if self._h:
+            lib().asx_comm_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
 
 
 class Stream:

@@ -445,6 +445,35 @@ def test_multi_plan_entry_point_partitions_and_orders_results(mod):
 
 # ---- more edge cases -------------------------------------------------------------------------
 
+def test_device_resident_shards_with_the_rccl_gather_inside_the_library(mod, torch):
+    """asx_comm_create / asx_xcorr_batch_multi_dev (SURVEY.md 8e behind the C-ABI): RCCL is dlopen()ed by the library,
+    ncclCommInitAll over the plans' devices, each shard runs on its device from its own host thread, ONE ncclAllGather
+    of the 20-byte result records.  One GPU is visible here, so the communicator has one rank (the driver's 8-GPU node
+    runs the torch.distributed form of bench.py); the records must hold the oracle's answers."""
+    n, count, width = 12000, 5, 8
+    d_src = torch.empty(count * 2 * n, dtype=torch.float32, device="cuda")
+    d_smp = torch.empty(count * n, dtype=torch.float32, device="cuda")
+    d_true = torch.empty(count, dtype=torch.int64, device="cuda")
+    mod.synth_pairs_dev(91, 0, count, n, 1, d_src.data_ptr(), d_smp.data_ptr(), d_true.data_ptr(), 0)
+    torch.cuda.synchronize()
+    rec = mod.result_bytes(width)
+    gathered = torch.full((rec,), 0x55, dtype=torch.uint8, device="cuda")
+    with mod.Plan(n, width, 0) as plan, mod.Comm([plan]) as comm:
+        comm.run([d_src.data_ptr()], [d_smp.data_ptr()], [count], width, [gathered.data_ptr()])
+        comm.run([d_src.data_ptr()], [d_smp.data_ptr()], [count], width, [gathered.data_ptr()])   # reusable
+    g = gathered.cpu().numpy()
+    lag = g[: 8 * width].view(np.int64); coef = g[8 * width: 16 * width].view(np.float64); ret = g[16 * width:].view(np.int32)
+    assert np.array_equal(lag[:count], d_true.cpu().numpy()) and not ret[:count].any()
+    assert not lag[count:].any() and not ret[count:].any()            # the padding of a short shard is zero
+    src = d_src.cpu().numpy().reshape(count, 2 * n); smp = d_smp.cpu().numpy().reshape(count, n)
+    for i in range(count):
+        o_ret, o_lag, o_coef = oracle.cross_correlation(src[i], smp[i])
+        assert o_ret == 0 and o_lag == int(lag[i]) and abs(o_coef - float(coef[i])) < COEF_TOL
+    with pytest.raises(mod.AsxError):
+        with mod.Plan(n, 1, 0) as a, mod.Plan(n, 1, 0) as b:
+            mod.Comm([a, b])                                            # one plan per device
+
+
 @pytest.mark.parametrize("n", [1, 2, 3, 4, 9, 3645])
 def test_tiny_and_odd_lengths(mod, n):
     """N = 1..4 (degenerate transforms), odd N with a smooth 2N (3645 = 3^6*5: pairs of an odd-length

@@ -101,3 +101,23 @@ def test_byte_buffer_gather_over_gloo(tmp_path):
         assert np.load(tmp_path / ("blag%d.npy" % r)).tolist() == [e[1] for e in expect]
         assert np.load(tmp_path / ("bret%d.npy" % r)).tolist() == [e[0] for e in expect]
         assert np.array_equal(np.load(tmp_path / ("bcoef%d.npy" % r)), np.array([e[2] for e in expect]))
+
+
+def test_c_abi_partition_matches_the_python_one():
+    """asx_shard_range (the block partition asx_xcorr_batch_multi_dev's callers use, include/audiosync/xcorr_hip.h) and
+    sharding.shard_range (bench.py, one process per GPU) are the same rule; the shards tile the batch in order."""
+    from util import asx
+    mod = asx()
+    from audiosync_amd import sharding
+    for total in (0, 1, 7, 8, 124, 8192, 8193):
+        for world in (1, 2, 3, 8):
+            nxt = 0
+            for r in range(world):
+                start, count = mod.shard_range(total, world, r)
+                assert (start, count) == sharding.shard_range(total, r, world)
+                assert start == nxt
+                nxt += count
+            assert nxt == total
+    assert mod.result_bytes(5) == 5 * 20
+    with pytest.raises(mod.AsxError):
+        mod.shard_range(10, 0, 0)
