@@ -574,9 +574,9 @@ static int repair_overflows(asx_plan *p, int lane, size_t g, const float *f_src,
         // the pair's transforms again, on the source minus its mean (k_rows recomputes the bound from the new norms
         // and zeroes the pair's running maximum and count); r = r' + stats[2]
         if (sizeof(TIn) == sizeof(float))
-            asx_launch_dc_remove_f32((const float *)p_src + i * 2 * N, (const float *)p_smp + i * N, P.N, B.stats, B.src_dc, s);
+            asx_launch_dc_remove_f32((const float *)p_src + i * 2 * N, (const float *)p_smp + i * N, P.N, (double)P.F, B.stats, B.src_dc, s);
         else
-            asx_launch_dc_remove_f64((const double *)p_src + i * 2 * N, (const double *)p_smp + i * N, P.N, B.stats, B.src_dc, s);
+            asx_launch_dc_remove_f64((const double *)p_src + i * 2 * N, (const double *)p_smp + i * N, P.N, (double)P.F, B.stats, B.src_dc, s);
         K.shift = B.stats + 2;
         asx_launch_fwd_cols(P, B.src_dc, f_smp + i * N, W.zxa + i * (size_t)P.M, W.zya + i * (size_t)P.M, K, 1, s);
         asx_launch_rows(P, W.zxa + i * (size_t)P.M, W.zya + i * (size_t)P.M, W.ga + i * (size_t)P.M, K, 1, s);

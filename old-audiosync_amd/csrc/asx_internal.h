@@ -138,10 +138,10 @@ void asx_launch_results_to_ms(const int64_t *lag, const double *coef, const int3
                               double min_confidence, double sample_rate, int64_t *lag_ms, int32_t *accept,
                               hipStream_t s);
 void asx_launch_cvt_f64_f32(const double *in, float *out, size_t n, hipStream_t s);
-// second look, DC removal: stats[0] = mean of source[0..2N), stats[1] = sum of sample[0..N), stats[2] = stats[0] * stats[1];
-// out[i] = (float)(source[i] - stats[0])
-void asx_launch_dc_remove_f32(const float *src, const float *smp, uint32_t N, double *stats, float *out, hipStream_t s);
-void asx_launch_dc_remove_f64(const double *src, const double *smp, uint32_t N, double *stats, float *out, hipStream_t s);
+// second look, DC removal: stats[0] = mean of source[0..2N), stats[1] = sum of sample[0..N), stats[2] = scale * stats[0] * stats[1]
+// (scale = F: the device's r is F times the plain sum of products); out[i] = (float)(source[i] - stats[0])
+void asx_launch_dc_remove_f32(const float *src, const float *smp, uint32_t N, double scale, double *stats, float *out, hipStream_t s);
+void asx_launch_dc_remove_f64(const double *src, const double *smp, uint32_t N, double scale, double *stats, float *out, hipStream_t s);
 void asx_launch_synth(uint64_t seed, uint64_t first_pair, size_t count, uint32_t N,
                       int noise_shift, float *src, float *smp, int64_t *true_lag, hipStream_t s);
 int asx_pick_threads(const AsxStages &st, int groups, int min_threads, size_t lds_bytes);

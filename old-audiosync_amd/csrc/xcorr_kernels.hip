@@ -1456,7 +1456,7 @@ __global__ __launch_bounds__(ASX_THREADS) void k_results_to_ms(const int64_t *__
 // ---------------------------------------------------------------------------
 template <typename TIn>
 __global__ __launch_bounds__(1024) void k_dc_stats(const TIn *__restrict__ src, const TIn *__restrict__ smp, uint32_t N,
-                                                    double *__restrict__ stats)
+                                                    double scale, double *__restrict__ stats)
 {
     __shared__ double red[2][16];
     double a = 0.0, b = 0.0;
@@ -1468,7 +1468,9 @@ __global__ __launch_bounds__(1024) void k_dc_stats(const TIn *__restrict__ src, 
     if (threadIdx.x == 0) {
         for (int w = 1; w < 16; w++) { a += red[0][w]; b += red[1][w]; }
         const double mean = a / (2.0 * (double)N);
-        stats[0] = mean; stats[1] = b; stats[2] = mean * b;
+        // the device's r is the unnormalised inverse transform, F times the plain sum of products (asx_api.hip,
+        // bound_scale): the constant that goes back into the keys carries the same factor
+        stats[0] = mean; stats[1] = b; stats[2] = mean * b * scale;
     }
 }
 template <typename TIn>
@@ -1820,14 +1822,14 @@ void asx_launch_cvt_f64_f32(const double *in, float *out, size_t n, hipStream_t 
     hipLaunchKernelGGL(k_cvt_f64_f32, dim3((unsigned)blocks), dim3(ASX_THREADS), 0, s, in, out, n);
 }
 
-void asx_launch_dc_remove_f32(const float *src, const float *smp, uint32_t N, double *stats, float *out, hipStream_t s)
+void asx_launch_dc_remove_f32(const float *src, const float *smp, uint32_t N, double scale, double *stats, float *out, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_dc_stats<float>, dim3(1), dim3(1024), 0, s, src, smp, N, stats);
+    hipLaunchKernelGGL(k_dc_stats<float>, dim3(1), dim3(1024), 0, s, src, smp, N, scale, stats);
     hipLaunchKernelGGL(k_dc_apply<float>, dim3(512), dim3(ASX_THREADS), 0, s, src, N, stats, out);
 }
-void asx_launch_dc_remove_f64(const double *src, const double *smp, uint32_t N, double *stats, float *out, hipStream_t s)
+void asx_launch_dc_remove_f64(const double *src, const double *smp, uint32_t N, double scale, double *stats, float *out, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_dc_stats<double>, dim3(1), dim3(1024), 0, s, src, smp, N, stats);
+    hipLaunchKernelGGL(k_dc_stats<double>, dim3(1), dim3(1024), 0, s, src, smp, N, scale, stats);
     hipLaunchKernelGGL(k_dc_apply<double>, dim3(512), dim3(ASX_THREADS), 0, s, src, N, stats, out);
 }
 

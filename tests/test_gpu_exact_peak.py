@@ -296,3 +296,28 @@ def test_offset_in_both_tracks_takes_the_mean_removed_second_look(mod, hostlib, 
             assert (int(ret_b[0]), int(lag_b[0])) == (0, d) and abs(float(coef_b[0]) - o_coef) < COEF_TOL
             if n > 6000 or plan.peak_capacity < 2 * n:
                 assert plan.peak_repairs() >= (1 if abs(ratio) >= 1e3 else 0)
+
+
+def test_moderate_offsets_where_the_shift_is_comparable_to_r(mod):
+    """The case tools/fuzz_parity.py found in round 3: a source offset of 20 .. 100 amplitudes that the sample inherits
+    (sample = 0.7 x shifted source).  The constant that the mean-removed second look adds back, mean * sum(sample), is
+    then of the same order as the correlation itself -- it has to carry the factor F of the device's unnormalised inverse
+    transform (k_dc_stats), or keys on either side of a sign change are ordered wrongly (float64 margin 4e-7 there)."""
+    n = 144000
+    rng = np.random.default_rng(2026)
+    repairs = 0
+    for off in (20.0, -47.0, 60.0, 100.0, -100.0, 300.0):
+        src = (rng.uniform(-1, 1, 2 * n) + off).astype(np.float32)
+        d = int(rng.integers(-n + 1, n))
+        idx = np.arange(n) + d
+        ok = (idx >= 0) & (idx < 2 * n)
+        smp = (np.where(ok, 0.7 * src[np.clip(idx, 0, 2 * n - 1)], 0.0) + 0.01 * rng.uniform(-1, 1, n)).astype(np.float32)
+        o_ret, o_lag, o_coef, o_r, margin = oracle.cross_correlation(src, smp, want_results=True)
+        if margin < 1.0 + 1e-10:
+            continue
+        with mod.Plan(n, 1, 0) as plan:
+            lag, coef, ret = plan.xcorr_batch_f32(src[None], smp[None])
+            repairs += plan.peak_repairs()
+        assert (int(ret[0]), int(lag[0])) == (o_ret, o_lag), (off, int(lag[0]), o_lag, margin)
+        assert abs(float(coef[0]) - o_coef) < COEF_TOL
+    assert repairs >= 2          # the larger offsets do take the second look

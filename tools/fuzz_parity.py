@@ -29,7 +29,7 @@ while time.time() - t0 < budget:
     elif r < 0.5: n = int(rng.choice([48000, 44100, 96000, 65536, 100000, 131072, 250000]))
     else: n = int(rng.integers(1, 20001))
     batch = int(rng.integers(1, 4)) if n < 100000 else 1
-    kind = int(rng.integers(0, 6))
+    kind = int(rng.integers(0, 8))
     i = np.arange(2 * n, dtype=np.float64)
     src = rng.uniform(-1, 1, (batch, 2 * n))
     if kind == 1:
@@ -38,18 +38,23 @@ while time.time() - t0 < budget:
     elif kind == 3: src = src + rng.uniform(-100, 100)
     elif kind == 4: src = np.sin(rng.uniform(0.001, 3.0) * i)[None, :] + 0.01 * src
     elif kind == 5: src = np.sign(np.sin(rng.uniform(0.01, 1.0) * i))[None, :] * np.ones((batch, 1)) + 1e-3 * src
+    elif kind == 6: src = src + 10.0 ** rng.uniform(2, 4) * rng.choice([-1, 1])     # a large offset; the sample gets one below
+    both_offset = 10.0 ** rng.uniform(2, 4) * rng.choice([-1, 1]) if kind == 6 else 0.0
+    silent = kind == 7 and rng.uniform() < 0.5
     smp = np.empty((batch, n))
     for b in range(batch):
         d = int(rng.integers(-n + 1, n)) if n > 1 else 0
         idx = np.arange(n) + d
         ok = (idx >= 0) & (idx < 2 * n)
         smp[b] = np.where(ok, rng.choice([0.7, -0.4]) * src[b, np.clip(idx, 0, 2 * n - 1)], 0.0) + rng.choice([0.0, 0.01, 0.3]) * rng.uniform(-1, 1, n)
+        if kind == 6: smp[b] = smp[b] - smp[b].mean() + both_offset                   # offsets of 1e2 .. 1e4 sigma in BOTH tracks
+        if silent: smp[b] = 0.0                                                       # a digitally silent capture
     s32, t32 = src.astype(np.float32), smp.astype(np.float32)
     with asx.Plan(n, batch, 0) as plan:
         lag, coef, ret = plan.xcorr_batch_f32(s32, t32)
     for b in range(batch):
         o_ret, o_lag, o_coef, o_r, margin = oracle.cross_correlation(s32[b], t32[b], want_results=True)
-        if margin < 1.0 + 1e-9:
+        if margin < 1.0 + (1e-11 if kind == 6 else 1e-9) and not silent:
             continue
         assert int(ret[b]) == o_ret, ("ret", trials, n, kind, b, int(ret[b]), o_ret)
         assert int(lag[b]) == o_lag, ("lag", trials, n, kind, b, int(lag[b]), o_lag, margin)
@@ -61,7 +66,7 @@ while time.time() - t0 < budget:
         lg = ctypes.c_long(0); cf = ctypes.c_double(0)
         rc = L.cross_correlation(s64.ctypes.data_as(dp), t64.ctypes.data_as(dp), n, ctypes.byref(lg), ctypes.byref(cf))
         o_ret, o_lag, o_coef, o_r, margin = oracle.cross_correlation(s64, t64, want_results=True)
-        if margin >= 1.0 + 1e-9:
+        if margin >= 1.0 + (1e-11 if kind == 6 else 1e-9) or silent:
             assert rc == o_ret and lg.value == o_lag, ("f64", trials, n, kind, rc, o_ret, lg.value, o_lag, margin)
             if o_ret == 0:
                 assert abs(cf.value - o_coef) < 1e-5, ("f64 coef", trials, n, cf.value, o_coef)
