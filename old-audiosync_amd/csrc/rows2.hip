@@ -27,9 +27,9 @@
 
 #include <stdlib.h>
 
-// Diagnostic ablations (-DASX_R2_ABL=<mask>, wrong results, timing only): 1 no HBM loads, 2 no butterflies,
-// 4 no twiddle / leg multiplications, 8 no combine arithmetic, 16 no HBM stores, 32 every block works on the rows of
-// task 1 of pair 0 (cache hits).
+// Diagnostic ablations (-DASX_R2_ABL=<mask>, wrong results, timing only; the numbers are in DESIGN.md 5.0): 1 no HBM
+// loads, 2 no butterflies, 4 no twiddle / leg multiplications, 8 no combine arithmetic, 32 every block works on the rows
+// of task 1 of pair 0 (cache hits).
 #ifndef ASX_R2_ABL
 #define ASX_R2_ABL 0
 #endif
@@ -94,7 +94,8 @@ __global__ __launch_bounds__(NT, ASX_ROWS2_WAVES) void k_rows2(const AsxDev *__r
                                                                 AsxPeakWs W)
 {
     constexpr int M2 = RA * RB, PT = RB + 1, RS = RA * PT; // row pitch and row-region size in float2 slots
-    // pass 2 strides 2*PT dwords from lane to lane: 32 distinct even banks for any odd... PT = RB + 1 with RB even
+    // pass 2 strides 2*PT dwords from lane to lane: with an odd pitch the 32 lanes of a ds_read_b64 group fall on 32
+    // different even banks
     static_assert(RB % 2 == 0, "the pitch RB + 1 must be odd");
     const AsxDev &PD = *Pp;
     const AsxKP P = asx_kp(PD);
@@ -308,7 +309,7 @@ __global__ __launch_bounds__(NT, ASX_ROWS2_WAVES) void k_rows2(const AsxDev *__r
         static_for<0, RA>([&](auto T) __attribute__((always_inline)) {
             constexpr int t = decltype(T)::value;
             const Cx1 y = (t == 0 || ((ASX_R2_ABL & 4) || FSX)) ? a[t] : mulwc(a[t], lg[t]);
-            if (!(ASX_R2_ABL & 16) || y.re == 1.2345e-30f) dst[t * RB] = make_float2(y.re, y.im);
+            dst[t * RB] = make_float2(y.re, y.im);
         });
     }
 }
@@ -319,7 +320,7 @@ __global__ __launch_bounds__(NT, ASX_ROWS2_WAVES) void k_rows2(const AsxDev *__r
 bool asx_launch_rows2(const AsxDev &P, const float2 *zxa, const float2 *zya, float2 *ga, const AsxPeakWs &W, int npairs,
                       hipStream_t s)
 {
-    // (ASX_ROWS2_OFF=1 in the environment makes plan creation leave tw2r null: the three-pass k_rows instead)
+    // (plan creation uploads tw2r only when the environment asks for this kernel, ASX_ROWS2=1: opt-in, asx_api.hip)
     if (!P.tw2r) return false;
     const int ntasks = (P.M1 / 2 + 1) * npairs;
 #define ASX_ROWS2_CASE(ra, rb, nt)                                                                                      \
