@@ -197,6 +197,11 @@ def side_mode(args):
         rng = np.random.default_rng(1)
         smp32 = (0.5 * src32[true_lag: true_lag + n_max] + 0.25 * rng.uniform(-1, 1, n_max)).astype(np.float32)
     src, smp = src32.astype(np.float64), smp32.astype(np.float64)
+    if args.mode == "streaming":
+        # the tracks live where audiosync_run() keeps them: page-locked host memory (host/audiosync.c, asx_host_malloc)
+        pin_src, pin_smp = asx.PinnedArray(src.size), asx.PinnedArray(smp.size)
+        pin_src.array[:] = src; pin_smp.array[:] = smp
+        src, smp = pin_src.array, pin_smp.array
     out = {"n_gpus": 1, "data": "synthetic", "dtype": "f32", "true_lag": int(true_lag)}
     if args.mode == "streaming":
         seconds = (3, 6, 10, 15, 20, 30)                       # src/audiosync.c:50-57

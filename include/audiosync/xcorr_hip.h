@@ -230,6 +230,11 @@ int asx_plan_last_timings_ms(asx_plan *plan, float out[6]);
 /* Raw device memory helpers so a C host (no torch) can stage buffers. */
 void *asx_device_malloc(size_t bytes, int device);
 int asx_device_free(void *ptr);
+/* Page-locked host memory: frames appended from it (asx_stream_append_f64) or passed to the host-array entry points travel
+ * by DMA without the runtime's bounce buffer.  The track buffers of audiosync_run() are allocated with it -- what
+ * fftw_alloc_real was to the reference's source buffer (src/audiosync.c:189): the allocation its backend wants. */
+void *asx_host_malloc(size_t bytes);
+int asx_host_free(void *ptr);
 int asx_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes);
 int asx_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes);
 int asx_stream_sync(asx_plan *plan, void *stream);

@@ -14,5 +14,5 @@ __graft_entry__.py (importlib), e.g.  `asx = __graft_entry__.load()`.
 from .hipxcorr import (  # noqa: F401
     LIB_PATH, AsxError, Plan, Stream, abi_version, device_count, lib, pearson_f64, planmath_candidates, planmath_describe,
     planmath_table, planmath_twiddles, results_to_ms_dev, synth_pairs_dev, xcorr_batch_multi,
-    Comm, result_bytes, shard_range,
+    Comm, PinnedArray, result_bytes, shard_range,
 )

@@ -1030,6 +1030,7 @@ struct asx_stream {
     double *d_coef = nullptr;
     int32_t *d_ret = nullptr;
     std::vector<asx_plan *> plans;  // one per prefix length seen
+    hipStream_t s = nullptr;        // uploads and conversions of new frames
     std::mutex lock;
 };
 
@@ -1040,6 +1041,7 @@ extern "C" void asx_stream_destroy(asx_stream *st)
     (void)hipGetDevice(&prev);
     (void)hipSetDevice(st->device);
     for (asx_plan *p : st->plans) asx_plan_destroy(p);
+    if (st->s) { (void)hipStreamSynchronize(st->s); (void)hipStreamDestroy(st->s); }
     (void)hipFree(st->src64); (void)hipFree(st->smp64); (void)hipFree(st->src32); (void)hipFree(st->smp32);
     (void)hipFree(st->d_lag); (void)hipFree(st->d_coef); (void)hipFree(st->d_ret);
     (void)hipSetDevice(prev);
@@ -1063,7 +1065,8 @@ extern "C" asx_stream *asx_stream_create(size_t max_sample_len, int device)
         hipMalloc((void **)&st->smp32, n * sizeof(float)) != hipSuccess ||
         hipMalloc((void **)&st->d_lag, sizeof(int64_t)) != hipSuccess ||
         hipMalloc((void **)&st->d_coef, sizeof(double)) != hipSuccess ||
-        hipMalloc((void **)&st->d_ret, sizeof(int32_t)) != hipSuccess) {
+        hipMalloc((void **)&st->d_ret, sizeof(int32_t)) != hipSuccess ||
+        hipStreamCreateWithFlags(&st->s, hipStreamNonBlocking) != hipSuccess) {
         fail("asx_stream_create: hipMalloc failed: %s", hipGetErrorString(hipGetLastError()));
         asx_stream_destroy(st);
         return nullptr;
@@ -1097,17 +1100,19 @@ extern "C" int asx_stream_append_f64(asx_stream *st, const double *source_frames
         return fail("asx_stream_append_f64: capacity exceeded");
     DevGuard dg(st->device);
     if (!dg.ok) return fail("cannot select device %d", st->device);
-    // the default stream orders these against the plans' streams through the blocking copies
+    // Both tracks' new frames go up on the stream's own HIP stream -- from page-locked memory (asx_host_malloc) by DMA,
+    // both copies and both conversions in flight together -- and one synchronisation orders them before the plans'
+    // streams, which only start after this function has returned.
     if (n_source) {
-        HIP_TRY(hipMemcpy(st->src64 + st->n_src, source_frames, n_source * sizeof(double), hipMemcpyHostToDevice));
-        asx_launch_cvt_f64_f32(st->src64 + st->n_src, st->src32 + st->n_src, n_source, nullptr);
+        HIP_TRY(hipMemcpyAsync(st->src64 + st->n_src, source_frames, n_source * sizeof(double), hipMemcpyHostToDevice, st->s));
+        asx_launch_cvt_f64_f32(st->src64 + st->n_src, st->src32 + st->n_src, n_source, st->s);
     }
     if (n_sample) {
-        HIP_TRY(hipMemcpy(st->smp64 + st->n_smp, sample_frames, n_sample * sizeof(double), hipMemcpyHostToDevice));
-        asx_launch_cvt_f64_f32(st->smp64 + st->n_smp, st->smp32 + st->n_smp, n_sample, nullptr);
+        HIP_TRY(hipMemcpyAsync(st->smp64 + st->n_smp, sample_frames, n_sample * sizeof(double), hipMemcpyHostToDevice, st->s));
+        asx_launch_cvt_f64_f32(st->smp64 + st->n_smp, st->smp32 + st->n_smp, n_sample, st->s);
     }
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(nullptr));
+    HIP_TRY(hipStreamSynchronize(st->s));
     st->n_src += n_source;
     st->n_smp += n_sample;
     return 0;
@@ -1231,6 +1236,23 @@ extern "C" void *asx_device_malloc(size_t bytes, int device)
 extern "C" int asx_device_free(void *ptr)
 {
     HIP_TRY(hipFree(ptr));
+    return 0;
+}
+
+extern "C" void *asx_host_malloc(size_t bytes)
+{
+    void *ptr = nullptr;
+    hipError_t e = hipHostMalloc(&ptr, bytes ? bytes : 1, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        fail("hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        return nullptr;
+    }
+    return ptr;
+}
+
+extern "C" int asx_host_free(void *ptr)
+{
+    if (ptr) HIP_TRY(hipHostFree(ptr));
     return 0;
 }
 

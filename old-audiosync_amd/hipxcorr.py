@@ -25,7 +25,7 @@ ABI_SYMBOLS = [
     "asx_plan_last_timings_ms", "asx_device_malloc", "asx_device_free", "asx_memcpy_h2d",
     "asx_memcpy_d2h", "asx_stream_sync", "asx_plan_peak_overflows", "asx_plan_peak_repairs", "asx_plan_set_exact", "asx_plan_peak_capacity",
     "asx_current_device", "asx_plan_timings_ms", "asx_xcorr_batch_multi",
-    "asx_shard_range", "asx_result_bytes", "asx_comm_create", "asx_comm_destroy", "asx_xcorr_batch_multi_dev",
+    "asx_host_malloc", "asx_host_free", "asx_shard_range", "asx_result_bytes", "asx_comm_create", "asx_comm_destroy", "asx_xcorr_batch_multi_dev",
 ]
 
 
@@ -132,6 +132,10 @@ def lib():
     L.asx_device_malloc.argtypes = [ctypes.c_size_t, ctypes.c_int]
     L.asx_device_free.restype = ctypes.c_int
     L.asx_device_free.argtypes = [vp]
+    L.asx_host_malloc.restype = vp
+    L.asx_host_malloc.argtypes = [ctypes.c_size_t]
+    L.asx_host_free.restype = ctypes.c_int
+    L.asx_host_free.argtypes = [vp]
     L.asx_memcpy_h2d.restype = ctypes.c_int
     L.asx_memcpy_h2d.argtypes = [vp, vp, ctypes.c_size_t]
     L.asx_memcpy_d2h.restype = ctypes.c_int
@@ -255,6 +259,24 @@ def xcorr_batch_multi(plans, source, sample):
     if rc != 0:
         raise AsxError(_err())
     return lag, coef, ret
+
+
+class PinnedArray:
+    """a numpy float64 array in page-locked host memory (asx_host_malloc): what audiosync_run() keeps its tracks in"""
+
+    def __init__(self, count, dtype=np.float64):
+        self.nbytes = int(count) * np.dtype(dtype).itemsize
+        self._p = lib().asx_host_malloc(self.nbytes)
+        if not self._p:
+            raise AsxError(_err())
+        buf = (ctypes.c_char * self.nbytes).from_address(self._p)
+        self.array = np.frombuffer(buf, dtype=dtype, count=int(count))
+
+    def close(self):
+        if self._p:
+            self.array = None
+            lib().asx_host_free(self._p)
+            self._p = None
 
 
 def shard_range(total, nshards, shard):

@@ -300,8 +300,10 @@ int audiosync_run(const char *yt_title, long *lag)
     double confidence;
     pthread_t cap_th, down_th;
     int cap_started = 0, down_started = 0;
-    double *sample = malloc(LEN_SAMPLE * sizeof(*sample));
-    double *source = malloc(LEN_SOURCE * sizeof(*source));
+    /* page-locked: every interval uploads the frames that are new since the previous one (the reference allocates its
+     * source with fftw_alloc_real, src/audiosync.c:189: the allocation its transform backend wants) */
+    double *sample = asx_host_malloc(LEN_SAMPLE * sizeof(*sample));
+    double *source = asx_host_malloc(LEN_SOURCE * sizeof(*source));
     struct ffmpeg_data cap_args = {
         .title = "", .buf = sample, .len = 0, .total_len = LEN_SAMPLE,
         .intervals = interv_sample, .n_intervals = N_INTERVALS,
@@ -388,8 +390,8 @@ finish:
     audiosync_abort();
     if (cap_started) pthread_join(cap_th, NULL);
     if (down_started) pthread_join(down_th, NULL);
-    free(sample);
-    free(source);
+    asx_host_free(sample);
+    asx_host_free(source);
     if (own_paths) { free(cap_pa.in.path); free(down_pa.in.path); }
     global_status = IDLE_ST;
     LOG("finished run");

@@ -67,6 +67,9 @@ static double pearson(const double *a, const double *b, size_t n)
     return sab / sqrt(saa * sbb);
 }
 
+void *asx_host_malloc(size_t bytes) { return malloc(bytes ? bytes : 1); }
+int asx_host_free(void *ptr) { free(ptr); return 0; }
+
 int asx_pearson_f64(const double *a, const double *b, size_t n, int device, double *out)
 {
     (void)device;
