@@ -78,3 +78,15 @@ def test_column_kernels_headline_keep_two_blocks_per_cu(kernels):
         (n, r), = [(n, r) for n, r in names.items() if n.startswith(prefix)]
         assert r["vgpr_count"] <= 128 and r["private_segment_fixed_size"] == 0, (n, r)
         assert 2 * (1200 * 8 * 8 + r["group_segment_fixed_size"]) <= 160 * 1024, (n, r)
+
+
+def test_two_pass_row_kernel_keeps_three_waves_per_simd_and_four_blocks_per_cu(kernels):
+    """k_rows2<30, 40, 192> (csrc/rows2.hip, opt-in): radix-30 / 40 single-member butterflies need more than 128
+    registers, so its budget is three waves per SIMD (<= 168 VGPRs; 138 today) with 192-thread blocks -- four blocks per
+    CU = 12 waves -- no scratch, and a static LDS image (4 rows of 30 x 41 float2 + the leg table) that fits four times."""
+    names = {demangled(k): v for k, v in kernels.items()}
+    rows2 = [(n, r) for n, r in names.items() if n.startswith("void k_rows2<30, 40, 192")]
+    assert rows2, sorted(names)[:8]
+    for n, r in rows2:
+        assert r["vgpr_count"] <= 168 and r["private_segment_fixed_size"] == 0, (n, r)
+        assert 4 * r["group_segment_fixed_size"] <= 160 * 1024, (n, r)
