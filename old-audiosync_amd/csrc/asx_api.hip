@@ -215,7 +215,7 @@ static int plan_init(asx_plan *p, size_t N, size_t max_batch, const char *split)
             dev_alloc(p, &ln.pk.pairmax, g) || dev_alloc(p, &ln.pk.cand_n, g) ||
             dev_alloc(p, &ln.pk.cand, g * cap) || dev_alloc(p, &ln.pk.refine_n, g) ||
             dev_alloc(p, &ln.pk.refine_idx, g * cap) || dev_alloc(p, &ln.pk.refine_val, g * cap) ||
-            dev_alloc(p, &ln.pk.overflows, 1) || dev_alloc(p, &ln.pk.ticket, 1) ||
+            dev_alloc(p, &ln.pk.overflows, 1) ||
             dev_alloc(p, &ln.seg, g) || dev_alloc(p, &ln.psums, g * ASX_PEARSON_BLOCKS * 6))
             return -1;
         HIP_TRY(hipMemset(ln.pk.overflows, 0, sizeof(unsigned long long)));
@@ -848,6 +848,7 @@ extern "C" int asx_xcorr_batch_multi_dev(asx_comm *c, const float *const *d_sour
             return fail("asx_xcorr_batch_multi_dev: shard %d: count %zu over width %zu, or a null pointer", i, counts[i], width);
     const size_t rec = asx_result_bytes(width);
     if (width != c->width) { // the shards' own result records, (re)sized to the width in use
+        c->width = 0; // a failure half-way leaves no record that the next call would take for a sized one
         for (int i = 0; i < n; i++) {
             DevGuard dg(c->plans[(size_t)i]->device);
             if (!dg.ok) return fail("cannot select device %d", c->plans[(size_t)i]->device);

@@ -111,8 +111,6 @@ struct AsxPeakWs {
     const double *shift;   // [pairs] or null: c with r[k] = (what the transforms deliver) + c for every k -- the second look at a pair
                            // runs the transforms on (source - mean), see repair_overflows; null / 0 everywhere else
     uint32_t cap;          // candidate capacity per pair
-    uint32_t *ticket;      // [1] task counter of a persistent k_rows launch (zeroed before the launch)
-    uint32_t ntasks_pairs; // pairs of the launch (filled in by the launcher)
 };
 
 void asx_launch_fwd_cols(const AsxDev &P, const float *src, const float *smp, float2 *zxa,

@@ -25,10 +25,6 @@
 
 #include <type_traits>
 
-#ifndef ASX_EXP_UNITTW
-#define ASX_EXP_UNITTW 0 /* experiment (wrong results): no stage twiddles at all, -25 % VALU work */
-#endif
-
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b)
 {
@@ -443,9 +439,7 @@ __device__ __forceinline__ void lds_stage(float4 *lds, const StageK K, const Lds
     const int ns = K.ns, q = K.q, nbf = K.nbf, twmul = K.twmul;
     const float inv_q = K.inv_q, inv_nbf = K.inv_nbf;
     const int total = L.ngroups * nbf;
-#ifndef ASX_EXP_NOCONF
     const int step = q * L.elem_stride;
-#endif
     for (int w = L.tid; w < total; w += L.nthreads) {
         int g, bf;
         if (GFAST) {
@@ -458,12 +452,7 @@ __device__ __forceinline__ void lds_stage(float4 *lds, const StageK K, const Lds
         if (UNIT_TW) { b = bf; j = 0; }                 // q == 1
         else if (nbf == q) { b = 0; j = bf; }           // first stage: one sub-block (wave-uniform test)
         else b = div_exact(bf, q, inv_q, j);
-#ifdef ASX_EXP_NOCONF /* experiment (wrong results): every stage addresses LDS like the first one, lanes on consecutive slots */
-        float4 *p = lds + g * L.group_stride + bf * L.elem_stride;
-        const int step = nbf * L.elem_stride;
-#else
         float4 *p = lds + g * L.group_stride + (b * ns + j) * L.elem_stride;
-#endif
         Cx2 v[R];
         if constexpr (std::is_same<typename std::decay<Source>::type, NoSource>::value)
             static_for<0, R>([&](auto T) __attribute__((always_inline)) { v[T] = lds_get(p + T * step); });
@@ -616,7 +605,7 @@ __device__ __forceinline__ void lds_stage_wavepair(float4 *lds, const LdsLayout 
             if (active) {
                 Cx2 v[R];
                 static_for<0, R>([&](auto T) __attribute__((always_inline)) { v[T] = lds_get(p + T * step); });
-                if constexpr (K.q == 1 || ASX_EXP_UNITTW) {
+                if constexpr (K.q == 1) {
                     Bfly<R, INV>::run(v);
                 } else {
                     float2 w1 = pre.w1, w4 = pre.w4;
@@ -709,7 +698,7 @@ __device__ __forceinline__ TwPre lds_fft_static_steps(float4 *lds, const LdsLayo
         } else {
             constexpr StageK K = S::stage(i);
             const TwPre next = tw_prefetch_exec<S, inext, GFAST, INV, HEAD>(L, tw);
-            lds_stage<K.R, INV, GFAST, K.q == 1 || ASX_EXP_UNITTW>(lds, K, L, tw, pre);
+            lds_stage<K.R, INV, GFAST, K.q == 1>(lds, K, L, tw, pre);
             pre = next;
             __syncthreads();
         }
@@ -789,21 +778,6 @@ __device__ __forceinline__ TwPre lds_fft_static_head_fed(float4 *lds, const LdsL
     lds_stage<K.R, INV, GFAST, K.q == 1>(lds, K, L, tw, pre, NoSink{}, source);
     __syncthreads();
     return lds_fft_static_steps<S, INV, GFAST, S::nstages - 1, true, 1>(lds, L, tw, next);
-}
-// Whole transform with its first stage fed by `source` (k_fwd_cols: the tile goes from HBM straight into
-// the first butterflies).  Ends with a barrier like lds_fft_static.
-template <class S, bool INV, bool GFAST, class Source>
-__device__ __forceinline__ void lds_fft_static_fed(float4 *lds, const LdsLayout &L, const float2 *__restrict__ tw, TwPre pre,
-                                                   Source &&source)
-{
-    constexpr int WPI = wave_pair_index<S, INV, false, GFAST>();
-    constexpr int i0 = INV ? S::nstages - 1 : 0, i1 = INV ? i0 - 1 : i0 + 1;
-    static_assert(WPI < 0 || (i0 != WPI && i0 != WPI + 1), "the fed stage must be a block-wide stage");
-    constexpr StageK K = S::stage(i0);
-    const TwPre next = tw_prefetch_exec<S, i1, GFAST, INV, false>(L, tw);
-    lds_stage<K.R, INV, GFAST, K.q == 1>(lds, K, L, tw, pre, NoSink{}, source);
-    __syncthreads();
-    (void)lds_fft_static_steps<S, INV, GFAST, S::nstages, false, 1>(lds, L, tw, next);
 }
 template <class S, bool INV, bool GFAST, class Sink>
 __device__ __forceinline__ void lds_last_stage_static(float4 *lds, const LdsLayout &L, const float2 *__restrict__ tw, TwPre pre,

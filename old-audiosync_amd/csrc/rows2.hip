@@ -27,12 +27,8 @@
 
 #include <stdlib.h>
 
-// Diagnostic ablations (-DASX_R2_ABL=<mask>, wrong results, timing only; the numbers are in DESIGN.md 5.0): 1 no HBM
-// loads, 2 no butterflies, 4 no twiddle / leg multiplications, 8 no combine arithmetic, 32 every block works on the rows
-// of task 1 of pair 0 (cache hits).
-#ifndef ASX_R2_ABL
-#define ASX_R2_ABL 0
-#endif
+// (The ablations whose numbers DESIGN.md 5.0 quotes -- no loads, no butterflies, no twiddles, no combine, cache-resident
+// rows -- are tools/experiments/kernel_switches.patch.)
 #ifndef ASX_ROWS2_WAVES
 #define ASX_ROWS2_WAVES 3 // launch bound: waves per SIMD = blocks per CU (4, by LDS) * NT / 256
 #endif
@@ -106,10 +102,9 @@ __global__ __launch_bounds__(NT, ASX_ROWS2_WAVES) void k_rows2(const AsxDev *__r
     const int task = blockIdx.x, tid = threadIdx.x;
     const int pair = task / nrows;
     const int4 rt = row_tasks[task - pair * nrows];
-    int pa = rt.x, pb = rt.y;
+    const int pa = rt.x, pb = rt.y;
     const int k1 = rt.z, m1 = rt.w;
     const bool self = (k1 == m1);
-    if (ASX_R2_ABL & 32) { pa = 1; pb = 2; }
     if (k1 == 0 && tid < 64) {
         // Row 0 of a pair also prepares the pair's peak search (as k_rows does): the float32 error bound from
         // the norms k_fwd_cols left, the running maximum and the candidate count back to zero.
@@ -123,11 +118,7 @@ __global__ __launch_bounds__(NT, ASX_ROWS2_WAVES) void k_rows2(const AsxDev *__r
             W.cand_n[pair] = 0;
         }
     }
-#ifdef ASX_EXP_PAIRMOD
-    const size_t wpair = (size_t)(pair % ASX_EXP_PAIRMOD);
-#else
-    const size_t wpair = (ASX_R2_ABL & 32) ? 0 : (size_t)pair;
-#endif
+    const size_t wpair = (size_t)pair;
     const float2 *gx = zxa + wpair * M, *gy = zya + wpair * M;
     float2 *go = ga + wpair * M;
     const uint32_t krow[2] = { (uint32_t)k1, (uint32_t)m1 };
@@ -142,9 +133,6 @@ __global__ __launch_bounds__(NT, ASX_ROWS2_WAVES) void k_rows2(const AsxDev *__r
     const bool has1 = tid < nfwd1;
     if (has1) {
         const float2 *src = ((r1 & 1) ? gy : gx) + (size_t)prow[r1 >> 1] * M2 + j1;
-        if (ASX_R2_ABL & 1)
-            static_for<0, RA>([&](auto T) __attribute__((always_inline)) { z[T] = make_float2((float)(tid + decltype(T)::value), (float)M); });
-        else
         static_for<0, RA>([&](auto T) __attribute__((always_inline)) { z[T] = src[decltype(T)::value * RB]; });
     }
     if (!FSX && tid < 2 * RA) {
@@ -159,15 +147,15 @@ __global__ __launch_bounds__(NT, ASX_ROWS2_WAVES) void k_rows2(const AsxDev *__r
         const float2 *lg = leg[r1 >> 1];
         static_for<0, RA>([&](auto T) __attribute__((always_inline)) {
             constexpr int t = decltype(T)::value;
-            a[t] = (t == 0 || ((ASX_R2_ABL & 4) || FSX)) ? Cx1{ z[t].x, z[t].y } : mulw(Cx1{ z[t].x, z[t].y }, lg[t]);
+            a[t] = (t == 0 || FSX) ? Cx1{ z[t].x, z[t].y } : mulw(Cx1{ z[t].x, z[t].y }, lg[t]);
         });
-        if (!(ASX_R2_ABL & 2)) Bfly<RA, false>::run(a);
+        Bfly<RA, false>::run(a);
         float2 tw[RA];
         rows2_twiddles<RA, FSX>(sd, tw);
         float2 *o = buf + r1 * RS + j1;
         static_for<0, RA>([&](auto U) __attribute__((always_inline)) {
             constexpr int u = decltype(U)::value;
-            const Cx1 y = (ASX_R2_ABL & 4) ? a[u] : mulw(a[u], tw[u]);
+            const Cx1 y = mulw(a[u], tw[u]);
             o[u * PT] = make_float2(y.re, y.im);
         });
     }
@@ -182,7 +170,7 @@ __global__ __launch_bounds__(NT, ASX_ROWS2_WAVES) void k_rows2(const AsxDev *__r
             float2 *p = buf + r * RS + u * PT;
             Cx1 v[RB];
             static_for<0, RB>([&](auto X) __attribute__((always_inline)) { const float2 t = p[decltype(X)::value]; v[X] = Cx1{ t.x, t.y }; });
-            if (!(ASX_R2_ABL & 2)) Bfly<RB, false>::run(v);
+            Bfly<RB, false>::run(v);
             static_for<0, RB>([&](auto X) __attribute__((always_inline)) { p[decltype(X)::value] = make_float2(v[X].re, v[X].im); });
         }
     }
@@ -209,13 +197,10 @@ __global__ __launch_bounds__(NT, ASX_ROWS2_WAVES) void k_rows2(const AsxDev *__r
             const float2 xa0 = Xa[a0], ya0 = Ya[a0], xb1 = Xb[a1], yb1 = Yb[a1];
             const float2 xa1 = Xa[a1], ya1 = Ya[a1], xb0 = Xb[a0], yb0 = Yb[a0];
             float2 gk0, gm0, gk1, gm1;
-            if (ASX_R2_ABL & 8) { gk0 = xa0; gm0 = yb1; gk1 = xa1; gm1 = yb0; }
-            else {
             combine_pair(Cx2{ v2f{ xa0.x, ya0.x }, v2f{ xa0.y, ya0.y } }, Cx2{ v2f{ xb1.x, yb1.x }, v2f{ xb1.y, yb1.y } },
                          cmul(wA, w2a), gk0, gm0);
             combine_pair(Cx2{ v2f{ xa1.x, ya1.x }, v2f{ xa1.y, ya1.y } }, Cx2{ v2f{ xb0.x, yb0.x }, v2f{ xb0.y, yb0.y } },
                          cmul(wA, w2b), gk1, gm1);
-            }
             if (mine) {
                 Xa[a0] = gk0; Xb[a1] = gm0; // G_k1 at slot s, G_m1 at slot s'
                 Xa[a1] = gk1; Xb[a0] = gm1;
@@ -281,7 +266,7 @@ __global__ __launch_bounds__(NT, ASX_ROWS2_WAVES) void k_rows2(const AsxDev *__r
             float2 *p = buf + 2 * g * RS + u * PT;
             Cx1 v[RB];
             static_for<0, RB>([&](auto X) __attribute__((always_inline)) { const float2 t = p[decltype(X)::value]; v[X] = Cx1{ t.x, t.y }; });
-            if (!(ASX_R2_ABL & 2)) Bfly<RB, true>::run(v);
+            Bfly<RB, true>::run(v);
             static_for<0, RB>([&](auto X) __attribute__((always_inline)) { p[decltype(X)::value] = make_float2(v[X].re, v[X].im); });
         }
     }
@@ -301,14 +286,14 @@ __global__ __launch_bounds__(NT, ASX_ROWS2_WAVES) void k_rows2(const AsxDev *__r
         static_for<0, RA>([&](auto U) __attribute__((always_inline)) {
             constexpr int u = decltype(U)::value;
             const float2 t = p[u * PT];
-            a[u] = (ASX_R2_ABL & 4) ? Cx1{ t.x, t.y } : mulwc(Cx1{ t.x, t.y }, tw[u]);
+            a[u] = mulwc(Cx1{ t.x, t.y }, tw[u]);
         });
-        if (!(ASX_R2_ABL & 2)) Bfly<RA, true>::run(a);
+        Bfly<RA, true>::run(a);
         const float2 *lg = leg[gi];
         float2 *dst = go + (size_t)prow[gi] * M2 + ji;
         static_for<0, RA>([&](auto T) __attribute__((always_inline)) {
             constexpr int t = decltype(T)::value;
-            const Cx1 y = (t == 0 || ((ASX_R2_ABL & 4) || FSX)) ? a[t] : mulwc(a[t], lg[t]);
+            const Cx1 y = (t == 0 || FSX) ? a[t] : mulwc(a[t], lg[t]);
             dst[t * RB] = make_float2(y.re, y.im);
         });
     }

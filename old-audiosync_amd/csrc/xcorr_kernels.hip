@@ -48,11 +48,6 @@
 #endif
 #define ASX_STAMP(slot) ASX_STAMP_AT(0, task, slot)
 
-// Diagnostic ablations of k_rows (-DASX_ABL=<mask>, wrong results, timing only): 1 no forward transforms,
-// 2 no spectral combine, 4 no inverse transforms, 8 every block reads and writes the rows of task 0 (cache hits).
-#ifndef ASX_ABL
-#define ASX_ABL 0
-#endif
 // ASX_NT bits (non-temporal accesses): 1 row loads of k_rows, 2 its row stores, 4 loads of the Pearson pass,
 // 8 tile stores of k_fwd_cols, 16 tile loads of k_inv_cols
 #ifndef ASX_NT
@@ -144,11 +139,7 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_fwd_cols(const AsxDe
     const float *in = is_smp ? smp + pair * (size_t)P.N : src + pair * (size_t)P.src_period;
     const uint32_t valid = is_smp ? P.N : P.src_valid;      // real samples that are not zero padding
     const uint32_t period = is_smp ? P.N : P.src_period;    // source may be periodically extended
-#ifdef ASX_EXP_PAIRMOD
-    float2 *out = (is_smp ? zya : zxa) + (pair % ASX_EXP_PAIRMOD) * (size_t)P.M;
-#else
     float2 *out = (is_smp ? zya : zxa) + pair * (size_t)P.M;
-#endif
     const bool even = (M2 & 1) == 0;
     const bool vec_in = even && ((reinterpret_cast<uintptr_t>(in) & 15u) == 0);
     float4 *lds4 = reinterpret_cast<float4 *>(asx_lds);
@@ -171,36 +162,6 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_fwd_cols(const AsxDe
     // sum of squares of everything this block loads: |source|^2 and |sample|^2 (the scale of the
     // float32 error bound of the peak search) come out of the pass that reads the inputs anyway
     float ss = 0.f;
-#ifndef ASX_FWD_FED
-#define ASX_FWD_FED 0 // experiment: first forward stage fed straight from HBM; measured 2 % SLOWER (1.07 -> 1.09 ms), unlike k_inv_cols
-#endif
-    bool transformed = false;
-    if constexpr (STATIC && ASX_FWD_FED) {
-        if (fast) { // block-uniform
-            // No fill phase: the first stage (legs M1/R rows apart) takes its inputs from HBM -- all of the
-            // thread's loads in flight together; rows in the zero padding are not loaded (the sample: the upper
-            // half of the legs) -- and writes its outputs to LDS: one LDS write + read pass and one barrier less.
-            ASX_STAMP_AT(1, stamp_block, 1);
-            lds_fft_static_fed<S1, false, true>(lds4, Lc, P.tw1, pre,
-                [&](auto RC, auto &v, int g, int pos0, int q) __attribute__((always_inline)) {
-                    const float *col = in + 2 * ((size_t)pos0 * M2 + c0 + 2 * g);
-                    float4 x[decltype(RC)::value];
-                    static_for<0, decltype(RC)::value>([&](auto TT) __attribute__((always_inline)) {
-                        constexpr int t = decltype(TT)::value;
-                        x[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (pos0 + t * q < data_rows) x[t] = *reinterpret_cast<const float4 *>(col + 2 * (size_t)(t * q) * M2);
-                    });
-                    static_for<0, decltype(RC)::value>([&](auto TT) __attribute__((always_inline)) {
-                        constexpr int t = decltype(TT)::value;
-                        ss = fmaf(x[t].x, x[t].x, fmaf(x[t].y, x[t].y, fmaf(x[t].z, x[t].z, fmaf(x[t].w, x[t].w, ss))));
-                        v[t] = Cx2{ v2f{ x[t].x, x[t].z }, v2f{ x[t].y, x[t].w } };
-                    });
-                });
-            // the norms: every barrier of the transform lies between these writes and the read below
-            transformed = true;
-        }
-    }
-    if (!transformed) {
     for (int e0 = threadIdx.x; e0 < nelem4; e0 += ASX_COL_LOADS * nthreads) {
         float4 v[ASX_COL_LOADS];
         if (fast) {
@@ -241,20 +202,15 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_fwd_cols(const AsxDe
             }
         });
     }
-    }
     ss = wave_sum_f32(ss);
-    if (transformed) {
-        // the transform has ended with a barrier; publish the wave sums behind one more
-        if ((threadIdx.x & 63) == 0) nrm_red[threadIdx.x >> 6] = ss;
-    } else {
     if ((threadIdx.x & 63) == 0) nrm_red[threadIdx.x >> 6] = ss;
     __syncthreads();
     ASX_STAMP_AT(1, stamp_block, 1);
+    // (the first stage fed straight from HBM, as in k_inv_cols, was measured 2 % slower here: this kernel is bound by its
+    // HBM access pattern, not by its LDS passes -- DESIGN.md 5.1, tools/experiments/kernel_switches.patch)
     if constexpr (STATIC) lds_fft_static<S1, false, true>(lds4, Lc, P.tw1, pre);
     else lds_fft<MAXR, false, true>(lds4, PD.st1, Lc, P.tw1, pre);
-    }
     ASX_STAMP_AT(1, stamp_block, 2);
-    if (transformed) __syncthreads(); // nrm_red written after the transform (block-uniform branch)
     if (threadIdx.x == 0) {
         float t = nrm_red[0];
         for (int w = 1; w < (nthreads + 63) >> 6; w++) t += nrm_red[w];
@@ -325,24 +281,15 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, ASX_ROWS_MIN_WAVES) void k_row
     float4 *A4 = reinterpret_cast<float4 *>(asx_lds), *B4 = A4 + M2;
     __shared__ float2 tw_step[2][ASX_ROW_STEPS];
 
-#ifndef ASX_ROWS_PERSIST
-#define ASX_ROWS_PERSIST 0 // 1: 4 blocks per CU that pull tasks from a ticket counter instead of one block per task
-#endif
-    // one task per block (grid = ntasks), or (ASX_ROWS_PERSIST) resident blocks that pull tasks: the first
-    // task of a block is its index, every further one a ticket taken one task ahead (the atomic's latency
-    // hides behind the task in progress)
-    __shared__ int s_next[2];
-    int task = blockIdx.x, iter = 0;
-    const int ntasks = ASX_ROWS_PERSIST ? nrows * (int)W.ntasks_pairs : (int)gridDim.x;
-    while (task < ntasks) {
-        int next_ticket = 0;
-        if (ASX_ROWS_PERSIST && threadIdx.x == 0) next_ticket = (int)gridDim.x + (int)atomicAdd(W.ticket, 1u);
+    // one task per block.  (Resident blocks that pull tasks from a ticket counter were measured: no gain, block start-up
+    // is not what this kernel waits for -- DESIGN.md 5.1, tools/experiments/kernel_switches.patch.)
+    const int task = blockIdx.x;
+    {
         const int pair = task / nrows;
         const int4 rt = row_tasks[task - pair * nrows];
-        int pa = rt.x, pb = rt.y;
+        const int pa = rt.x, pb = rt.y;
         const int k1 = rt.z, m1 = rt.w;
         const bool self = (k1 == m1);
-        if (ASX_ABL & 8) { pa = 1; pb = 2; }
         ASX_STAMP(0);
         if (k1 == 0 && threadIdx.x < 64) {
             // Row 0 of a pair also prepares the pair's peak search (k_inv_cols runs after this kernel):
@@ -360,11 +307,7 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, ASX_ROWS_MIN_WAVES) void k_row
         }
         LdsLayout Lf;
         Lf.ngroups = self ? 1 : 2; Lf.log_ngroups = 0;
-        // Per-thread table reads (stage twiddles, four-step twiddles) depend on the thread index only; in the
-        // persistent form the compiler would hoist them all out of the task loop (128 VGPRs + spills), so the
-        // loop body sees an opaque copy of the index.
-        int tid = threadIdx.x;
-        if (ASX_ROWS_PERSIST) asm volatile("" : "+v"(tid));
+        const int tid = threadIdx.x;
         Lf.elem_stride = 1; Lf.group_stride = M2; Lf.nthreads = nthreads; Lf.tid = tid;
         LdsLayout Li;
         Li.ngroups = 1; Li.log_ngroups = 0;
@@ -377,22 +320,8 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, ASX_ROWS_MIN_WAVES) void k_row
         const int half = M2 >> 1; // wide: a thread owns the element pairs q = t + nthreads*i, j2 = 2q, 2q+1
         RowRegs L;
         RowRegsWide LW;
-#ifndef ASX_ROWS_FED
-#define ASX_ROWS_FED 0 // experiment: first forward row stage fed straight from HBM; no difference [measured 1.18-1.20 ms both], +8 VGPRs
-#endif
-        bool fed = false; // block-uniform
-        if constexpr (STATIC && ASX_ROWS_FED) fed = !self;
-#ifdef ASX_EXP_PAIRMOD
-        const float2 *gxf = zxa + (size_t)(pair % ASX_EXP_PAIRMOD) * M, *gyf = zya + (size_t)(pair % ASX_EXP_PAIRMOD) * M;
-#else
-        const float2 *gxf = zxa + (size_t)pair * M, *gyf = zya + (size_t)pair * M;
-#endif
-        if (!fed) {
-#ifdef ASX_EXP_PAIRMOD /* experiment (wrong results): the intermediates of all pairs fall on those of the first ASX_EXP_PAIRMOD pairs (Infinity-Cache resident) */
-            const float2 *gx = zxa + (size_t)(pair % ASX_EXP_PAIRMOD) * M, *gy = zya + (size_t)(pair % ASX_EXP_PAIRMOD) * M;
-#else
+        {
             const float2 *gx = zxa + (size_t)pair * M, *gy = zya + (size_t)pair * M;
-#endif
             if (wide) {
                 static_for<0, ASX_ROW_WSTEPS>([&](auto I) __attribute__((always_inline)) {
                     const int q = tid + decltype(I)::value * nthreads;
@@ -441,43 +370,9 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, ASX_ROWS_MIN_WAVES) void k_row
         const float2 twa = tw_F(P, 2u * (uint32_t)k1 * tcol);
         const float2 twb = tw_F(P, 2u * (uint32_t)m1 * tcol);
         const float2 wk1 = tw_F(P, 2u * (uint32_t)k1), wm1 = tw_F(P, 2u * (uint32_t)m1); // w_M^k1, w_M^m1
-        bool fwd_done = false;
-        if constexpr (STATIC && ASX_ROWS_FED) {
-            if (fed) {
-                // No fill phase: the first row stage (legs q0 = M2/R0 elements apart) takes its inputs from HBM --
-                // 2*R0 eight-byte loads per thread, all in flight together -- times the four-step twiddle
-                // w_M^(row*(j + q0*t)) = w_M^(row*j) (one lookup per thread) * w_M^(row*q0*t) (R0 values per row,
-                // block-uniform, from LDS), and writes its outputs to LDS: one LDS write + read pass and one
-                // barrier less per block.
-                constexpr StageK K0 = S2::stage(0);
-                __shared__ float2 tw_leg[2][K0.R];
-                if (tid < 2 * K0.R) {
-                    const int which = tid >= K0.R;
-                    const int t = tid - which * K0.R;
-                    tw_leg[which][t] = tw_F(P, 2u * (which ? (uint32_t)m1 : (uint32_t)k1) * (uint32_t)(K0.q * t));
-                }
-                __syncthreads(); // tw_leg (and tw_step for the store phase) visible
-                ASX_STAMP(1);
-                lds_fft_static_fed<S2, false, false>(A4, Lf, P.tw2, pre_f,
-                    [&](auto RC, auto &v, int g, int pos0, int q) __attribute__((always_inline)) {
-                        constexpr int R = decltype(RC)::value;
-                        const size_t ro = (size_t)(g ? pb : pa) * M2 + pos0;
-                        float2 x[R], y[R];
-                        static_for<0, R>([&](auto TT) __attribute__((always_inline)) {
-                            constexpr int t = decltype(TT)::value;
-                            x[t] = gxf[ro + t * q];
-                            y[t] = gyf[ro + t * q];
-                        });
-                        const float2 base = tw_F(P, 2u * (g ? (uint32_t)m1 : (uint32_t)k1) * (uint32_t)pos0);
-                        static_for<0, R>([&](auto TT) __attribute__((always_inline)) {
-                            constexpr int t = decltype(TT)::value;
-                            v[t] = mulw(Cx2{ v2f{ x[t].x, y[t].x }, v2f{ x[t].y, y[t].y } }, cmul(base, tw_leg[g][t]));
-                        });
-                    });
-                fwd_done = true;
-            }
-        }
-        if (!fwd_done) {
+        // (The first row stage fed straight from HBM, as in k_inv_cols, made no difference here: 1.18-1.20 ms with and
+        // without, +8 VGPRs -- DESIGN.md 5.1, tools/experiments/kernel_switches.patch.)
+        {
             __syncthreads();
             if (wide) {
                 static_for<0, ASX_ROW_WSTEPS>([&](auto I) __attribute__((always_inline)) {
@@ -509,20 +404,15 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, ASX_ROWS_MIN_WAVES) void k_row
             }
         __syncthreads();
         ASX_STAMP(1);
-        if (!(ASX_ABL & 1)) {
         if constexpr (STATIC) lds_fft_static<S2, false, false>(A4, Lf, P.tw2, pre_f);
         else lds_fft<MAXR, false, false>(A4, PD.st2, Lf, P.tw2, pre_f);
-        }
         }
         ASX_STAMP(2);
 
         // ---- spectral combine: the same storage then holds C[e] = {Ga[e], Gb[e]}, the two rows of G.
         const float2 wA = wk1; // w_M^k1, block-uniform; w_M^(k1 + M1*k2) = wA * w_M2^k2
         TwPre pre_i;
-        if ((ASX_ABL & 2) && !self) {
-            if constexpr (STATIC) pre_i = tw_prefetch_first<S2, true, false>(Li, P.tw2);
-            else pre_i = tw_prefetch<false>(PD.st2, PD.st2.nstages - 1, Li, P.tw2);
-        } else if (!self) {
+        if (!self) {
             // The common case.  A thread walks SLOT PAIRS (s, s' = M2-1-s), s = t + i*nthreads < M2/2, not bins:
             // digit reversal complements every digit, so the partner bin M2-1-k2 of the bin at slot s sits at
             // slot s'.  Bin(s) of row k1 pairs with bin(s') of row m1 and bin(s') of row k1 with bin(s) of row
@@ -578,8 +468,7 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, ASX_ROWS_MIN_WAVES) void k_row
             const int k2 = tid + i * nthreads;
             sa[i] = -1; sb[i] = -1;
             gk[i] = make_float2(0.f, 0.f); gm[i] = make_float2(0.f, 0.f);
-            if (ASX_ABL & 2) {
-            } else if (k1 == 0) {
+            if (k1 == 0) {
                 if (k2 == 0) {
                     // DC and Nyquist bins are real: X[0] = Re Z0 + Im Z0, X[M] = Re Z0 - Im Z0
                     const Cx2 z = lds_get(A4);
@@ -617,21 +506,15 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, ASX_ROWS_MIN_WAVES) void k_row
 
         ASX_STAMP(3);
         // inverse row transforms of the G pair, digit-reversed in -> natural j2 out
-        if (!(ASX_ABL & 4)) {
         if constexpr (STATIC) lds_fft_static<S2, true, false>(A4, Li, P.tw2, pre_i);
         else lds_fft<MAXR, true, false>(A4, PD.st2, Li, P.tw2, pre_i);
-        }
         ASX_STAMP(4);
 
         // inverse four-step twiddle conj(w_M^(k1*j2)) / conj(w_M^(m1*j2)), one per member; unrolled so
         // that the LDS reads of all steps are in flight together (a rolled loop pays the LDS latency
         // once per step).  twa / twb ride in registers from the load phase.  Even rows leave as 16
         // bytes per lane, like they came.
-#ifdef ASX_EXP_PAIRMOD
-        float2 *go = ga + (size_t)(pair % ASX_EXP_PAIRMOD) * M;
-#else
         float2 *go = ga + (size_t)pair * M;
-#endif
         if (wide) {
             Cx2 g0[ASX_ROW_WSTEPS], g1[ASX_ROW_WSTEPS];
             static_for<0, ASX_ROW_WSTEPS>([&](auto I) __attribute__((always_inline)) {
@@ -673,11 +556,6 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, ASX_ROWS_MIN_WAVES) void k_row
             });
         }
         ASX_STAMP(5);
-        if (!ASX_ROWS_PERSIST) break;
-        if (threadIdx.x == 0) s_next[iter & 1] = next_ticket;
-        __syncthreads(); // the ticket is visible, and nobody still reads this task's rows from LDS
-        task = s_next[iter & 1];
-        iter++;
     }
 }
 
@@ -816,11 +694,7 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_inv_cols(const AsxDe
     const double shift = W.shift ? W.shift[pair] : 0.0; // block-uniform; non-zero only in the second look (repair_overflows)
     const int logH = logT - 1, H = T >> 1, M2 = P.M2;
     const int c0 = tile * T;
-#ifdef ASX_EXP_PAIRMOD
-    const float2 *in = ga + (pair % ASX_EXP_PAIRMOD) * (size_t)P.M;
-#else
     const float2 *in = ga + pair * (size_t)P.M;
-#endif
     const bool even = (M2 & 1) == 0;
     float4 *lds4 = reinterpret_cast<float4 *>(asx_lds);
 
@@ -1621,25 +1495,7 @@ void asx_launch_fwd_cols_generic(const AsxDev &P, const float *src, const float 
 
 #define ASX_ROWS_LAUNCH(...) \
     do { allow_big_lds((const void *)k_rows<__VA_ARGS__>, lds); \
-         AsxPeakWs Wk = W; Wk.ntasks_pairs = (uint32_t)npairs; \
-         int grid = ntasks; \
-         if (ASX_ROWS_PERSIST) { \
-             int per_cu = 0; \
-             (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_rows<__VA_ARGS__>, P.threads_rows, lds); \
-             grid = std::min(ntasks, std::max(1, per_cu) * asx_cu_count()); \
-             (void)hipMemsetAsync(W.ticket, 0, sizeof(uint32_t), s); \
-         } \
-         hipLaunchKernelGGL((k_rows<__VA_ARGS__>), dim3(grid), dim3(P.threads_rows), lds, s, P.self_dev, zxa, zya, ga, P.row_tasks, P.M1, P.M2, P.M, Wk); } while (0)
-static int asx_cu_count()
-{
-    static int n = 0;
-    if (n > 0) return n;
-    int dev = 0, c = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return 256;
-    if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c < 1) return 256;
-    n = c;
-    return n;
-}
+         hipLaunchKernelGGL((k_rows<__VA_ARGS__>), dim3(ntasks), dim3(P.threads_rows), lds, s, P.self_dev, zxa, zya, ga, P.row_tasks, P.M1, P.M2, P.M, W); } while (0)
 static size_t rows_lds_request(const AsxDev &P)
 {
     size_t lds = lds_bytes_rows(P);
