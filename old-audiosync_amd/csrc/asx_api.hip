@@ -216,7 +216,7 @@ static int plan_init(asx_plan *p, size_t N, size_t max_batch, const char *split)
             dev_alloc(p, &ln.pk.cand, g * cap) || dev_alloc(p, &ln.pk.refine_n, g) ||
             dev_alloc(p, &ln.pk.refine_idx, g * cap) || dev_alloc(p, &ln.pk.refine_val, g * cap) ||
             dev_alloc(p, &ln.pk.overflows, 1) ||
-            dev_alloc(p, &ln.seg, g) || dev_alloc(p, &ln.psums, g * ASX_PEARSON_BLOCKS * 6))
+            dev_alloc(p, &ln.seg, g) || dev_alloc(p, &ln.psums, std::max(g * ASX_PEARSON_BLOCKS, (size_t)ASX_PEARSON_BLOCKS_MAX) * 6))
             return -1;
         HIP_TRY(hipMemset(ln.pk.overflows, 0, sizeof(unsigned long long)));
         HIP_TRY(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
@@ -511,10 +511,10 @@ static int run_group(asx_plan *p, const float *d_src, const float *d_smp, const 
     if (prof_mark(p, s, e0 + 4)) return -1;
     if (sizeof(TIn) == sizeof(float))
         asx_launch_pearson_f32((const float *)p_src, (const float *)p_smp, 2 * (size_t)P.N, P.N, P.N,
-                               W.seg, W.psums, d_lag, d_coef, d_ret, (int)g, s);
+                               W.seg, W.psums, std::max(p->group * ASX_PEARSON_BLOCKS, (size_t)ASX_PEARSON_BLOCKS_MAX), d_lag, d_coef, d_ret, (int)g, s);
     else
         asx_launch_pearson_f64((const double *)p_src, (const double *)p_smp, 2 * (size_t)P.N, P.N, P.N,
-                               W.seg, W.psums, d_lag, d_coef, d_ret, (int)g, s);
+                               W.seg, W.psums, std::max(p->group * ASX_PEARSON_BLOCKS, (size_t)ASX_PEARSON_BLOCKS_MAX), d_lag, d_coef, d_ret, (int)g, s);
     if (prof_mark(p, s, e0 + 5)) return -1;
     HIP_TRY(hipGetLastError());
     return 0;
@@ -589,10 +589,10 @@ static int repair_overflows(asx_plan *p, int lane, size_t g, const float *f_src,
         double *ps = W.psums + i * ASX_PEARSON_BLOCKS * 6;
         if (sizeof(TIn) == sizeof(float))
             asx_launch_pearson_f32((const float *)p_src + i * 2 * N, (const float *)p_smp + i * N, 2 * N, N, P.N,
-                                   W.seg + i, ps, d_lag ? d_lag + i : nullptr, d_coef + i, d_ret ? d_ret + i : nullptr, 1, s);
+                                   W.seg + i, ps, ASX_PEARSON_BLOCKS, d_lag ? d_lag + i : nullptr, d_coef + i, d_ret ? d_ret + i : nullptr, 1, s);
         else
             asx_launch_pearson_f64((const double *)p_src + i * 2 * N, (const double *)p_smp + i * N, 2 * N, N, P.N,
-                                   W.seg + i, ps, d_lag ? d_lag + i : nullptr, d_coef + i, d_ret ? d_ret + i : nullptr, 1, s);
+                                   W.seg + i, ps, ASX_PEARSON_BLOCKS, d_lag ? d_lag + i : nullptr, d_coef + i, d_ret ? d_ret + i : nullptr, 1, s);
         HIP_TRY(hipGetLastError());
         p->repaired++;
     }
@@ -970,7 +970,7 @@ extern "C" int asx_pearson_f64(const double *a, const double *b, size_t n, int d
         double *ps = nullptr, *c = nullptr;
         AsxSeg *seg = nullptr;
         if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess ||
-            hipMalloc((void **)&ps, ASX_PEARSON_BLOCKS * 6 * sizeof(double)) != hipSuccess ||
+            hipMalloc((void **)&ps, ASX_PEARSON_BLOCKS_MAX * 6 * sizeof(double)) != hipSuccess ||
             hipMalloc((void **)&c, sizeof(double)) != hipSuccess || hipMalloc((void **)&seg, sizeof(AsxSeg)) != hipSuccess) {
             const hipError_t e = hipGetLastError();
             if (st) (void)hipStreamDestroy(st);
@@ -996,7 +996,7 @@ extern "C" int asx_pearson_f64(const double *a, const double *b, size_t n, int d
     HIP_TRY(hipMemcpyAsync(S.a, a, n * sizeof(double), hipMemcpyHostToDevice, S.stream));
     HIP_TRY(hipMemcpyAsync(S.b, b, n * sizeof(double), hipMemcpyHostToDevice, S.stream));
     HIP_TRY(hipMemcpyAsync(S.seg, &seg, sizeof(seg), hipMemcpyHostToDevice, S.stream));
-    asx_launch_pearson_f64(S.a, S.b, 0, 0, (uint32_t)n, S.seg, S.ps, nullptr, S.c, nullptr, 1, S.stream);
+    asx_launch_pearson_f64(S.a, S.b, 0, 0, (uint32_t)n, S.seg, S.ps, ASX_PEARSON_BLOCKS_MAX, nullptr, S.c, nullptr, 1, S.stream);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out, S.c, sizeof(double), hipMemcpyDeviceToHost, S.stream));
     HIP_TRY(hipStreamSynchronize(S.stream));

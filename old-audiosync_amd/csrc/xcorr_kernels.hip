@@ -1215,12 +1215,9 @@ __global__ __launch_bounds__(ASX_THREADS) void k_pearson_partial(const TIn *__re
     __shared__ double red[6][ASX_THREADS / 64];
     const size_t pair = blockIdx.y;
     const AsxSeg s = seg[pair];
-    // gridDim.x <= ASX_PEARSON_BLOCKS partial blocks per pair (asx_pearson_blocks); the final kernel always
-    // merges ASX_PEARSON_BLOCKS entries, so block 0 marks the unused ones as empty (n = 0)
-    if (blockIdx.x == 0 && threadIdx.x >= gridDim.x && threadIdx.x < ASX_PEARSON_BLOCKS) {
-        double *z = psums + (pair * ASX_PEARSON_BLOCKS + threadIdx.x) * 6;
-        z[0] = z[1] = z[2] = z[3] = z[4] = z[5] = 0.0;
-    }
+    // gridDim.x partial blocks per pair (asx_pearson_blocks: 64 at most for a batch that fills the chip anyway, up to
+    // ASX_PEARSON_BLOCKS_MAX for a few pairs, whose pass is otherwise a chain of a few blocks' load latencies); the
+    // final kernel merges exactly gridDim.x entries
     const uint32_t chunk = (basis_len + gridDim.x - 1) / gridDim.x;
     const uint64_t lo = (uint64_t)blockIdx.x * chunk;
     uint64_t hi = lo + chunk;
@@ -1277,22 +1274,31 @@ __global__ __launch_bounds__(ASX_THREADS) void k_pearson_partial(const TIn *__re
             o.mxx = red[3][w]; o.myy = red[4][w]; o.cxy = red[5][w];
             v = pstat_merge(v, o);
         }
-        double *out = psums + (pair * ASX_PEARSON_BLOCKS + blockIdx.x) * 6;
+        double *out = psums + (pair * gridDim.x + blockIdx.x) * 6;
         out[0] = v.n; out[1] = v.mx; out[2] = v.my; out[3] = v.mxx; out[4] = v.myy; out[5] = v.cxy;
     }
 }
 
-// grid (npairs), one wave per pair: lane b owns partial block b.
+// grid (npairs), one wave per pair: lane b owns the partial blocks b, b + 64, ... (merged in that order: a fixed tree for a
+// given block count, the same for x and y).
+// (Pick, partial sums and this merge as ONE kernel -- the last block to arrive at a per-pair counter merges -- was
+// measured: the release-acquire increment per block took the batch pass from 0.20 to 0.60 ms and the single pair
+// gained nothing, its latency is the chain of dependent loads inside the kernels, not their number.)
 __global__ __launch_bounds__(64) void k_pearson_final(const AsxSeg *__restrict__ seg,
-                                                       const double *__restrict__ psums,
+                                                       const double *__restrict__ psums, uint32_t nb,
                                                        int64_t *__restrict__ lag,
                                                        double *__restrict__ coef,
                                                        int32_t *__restrict__ ret)
 {
     const size_t pair = blockIdx.x;
-    const double *p = psums + (pair * ASX_PEARSON_BLOCKS + threadIdx.x) * 6;
     PStat v;
-    v.n = p[0]; v.mx = p[1]; v.my = p[2]; v.mxx = p[3]; v.myy = p[4]; v.cxy = p[5];
+    v.n = v.mx = v.my = v.mxx = v.myy = v.cxy = 0.0;
+    for (uint32_t b = threadIdx.x; b < nb; b += 64u) {
+        const double *p = psums + (pair * nb + b) * 6;
+        PStat o;
+        o.n = p[0]; o.mx = p[1]; o.my = p[2]; o.mxx = p[3]; o.myy = p[4]; o.cxy = p[5];
+        v = pstat_merge(v, o);
+    }
     v = pstat_wave_merge(v);
     if (threadIdx.x == 0) {
         const AsxSeg s = seg[pair];
@@ -1634,31 +1640,44 @@ void asx_launch_refine_f64(const AsxDev &P, const double *src, const double *smp
 // Partial blocks per pair: at least 16 sweeps of the block over its chunk (a block that only makes two
 // pays more for its reduction than for its loads: 1024 pairs of N = 144 000 ran at 3.0 TB/s with 64
 // blocks per pair against 5.7 TB/s at N = 1 440 000), at most ASX_PEARSON_BLOCKS.
-static unsigned asx_pearson_blocks(uint32_t basis_len)
+// ... unless the launch is so small (a single pair, the second look) that the chip would sit idle behind a few blocks'
+// chains of load latencies: then as many as give every thread one step, up to what the partial-sum buffer (`room`
+// entries for the launch) holds (single pair of N = 1 440 000: 21.5 -> 17.9 us)
+static unsigned asx_pearson_blocks(uint32_t basis_len, int npairs, size_t room)
 {
     const uint32_t per_block = 16u * 4u * ASX_THREADS;
     uint32_t nb = (basis_len + per_block - 1) / per_block;
-    if (nb < 1) nb = 1;
     if (nb > ASX_PEARSON_BLOCKS) nb = ASX_PEARSON_BLOCKS;
+    if ((size_t)nb * (size_t)npairs < 2048u) {
+        const uint32_t one_step = (basis_len + 4u * ASX_THREADS - 1) / (4u * ASX_THREADS);
+        uint32_t want = (uint32_t)(2048u / (unsigned)npairs);
+        if (want > ASX_PEARSON_BLOCKS_MAX) want = ASX_PEARSON_BLOCKS_MAX;
+        if (want > one_step) want = one_step;
+        if (want > nb) nb = want;
+    }
+    if ((size_t)nb * (size_t)npairs > room) nb = (uint32_t)(room / (size_t)npairs);
+    if (nb < 1) nb = 1;
     return nb;
 }
 
 void asx_launch_pearson_f32(const float *src, const float *smp, size_t src_pitch, size_t smp_pitch,
-                            uint32_t basis_len, const AsxSeg *seg, double *psums, int64_t *lag,
+                            uint32_t basis_len, const AsxSeg *seg, double *psums, size_t psums_room, int64_t *lag,
                             double *coef, int32_t *ret, int npairs, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_pearson_partial<float>, dim3(asx_pearson_blocks(basis_len), npairs), dim3(ASX_THREADS), 0, s,
+    const unsigned nb = asx_pearson_blocks(basis_len, npairs, psums_room);
+    hipLaunchKernelGGL(k_pearson_partial<float>, dim3(nb, npairs), dim3(ASX_THREADS), 0, s,
                        src, smp, src_pitch, smp_pitch, basis_len, seg, psums);
-    hipLaunchKernelGGL(k_pearson_final, dim3(npairs), dim3(64), 0, s, seg, psums, lag, coef, ret);
+    hipLaunchKernelGGL(k_pearson_final, dim3(npairs), dim3(64), 0, s, seg, psums, nb, lag, coef, ret);
 }
 
 void asx_launch_pearson_f64(const double *src, const double *smp, size_t src_pitch, size_t smp_pitch,
-                            uint32_t basis_len, const AsxSeg *seg, double *psums, int64_t *lag,
+                            uint32_t basis_len, const AsxSeg *seg, double *psums, size_t psums_room, int64_t *lag,
                             double *coef, int32_t *ret, int npairs, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_pearson_partial<double>, dim3(asx_pearson_blocks(basis_len), npairs), dim3(ASX_THREADS), 0, s,
+    const unsigned nb = asx_pearson_blocks(basis_len, npairs, psums_room);
+    hipLaunchKernelGGL(k_pearson_partial<double>, dim3(nb, npairs), dim3(ASX_THREADS), 0, s,
                        src, smp, src_pitch, smp_pitch, basis_len, seg, psums);
-    hipLaunchKernelGGL(k_pearson_final, dim3(npairs), dim3(64), 0, s, seg, psums, lag, coef, ret);
+    hipLaunchKernelGGL(k_pearson_final, dim3(npairs), dim3(64), 0, s, seg, psums, nb, lag, coef, ret);
 }
 
 void asx_launch_results_to_ms(const int64_t *lag, const double *coef, const int32_t *ret, size_t batch,
