@@ -186,6 +186,29 @@ def test_batch_larger_than_group(mod):
     run_batch_against_oracle(mod, 6000, 10, 1, seed=9, max_batch=3)
 
 
+def test_coefficient_does_not_depend_on_the_shape_of_the_launch(mod):
+    """The Pearson pass cuts a pair into up to 512 partial blocks when a launch has only a few pairs and into at most 64 in a
+    full batch (asx_pearson_blocks): the same pair alone, in a small batch and in a large one -- same lag, coefficients
+    equal to rounding, all within the tolerance of the oracle's."""
+    n, delay = 96000, 777
+    rng = np.random.default_rng(123)
+    src = rng.uniform(-1, 1, 2 * n).astype(np.float32) + np.float32(0.25)
+    smp = (0.5 * src[delay: delay + n] + 0.2 * rng.uniform(-1, 1, n)).astype(np.float32)
+    o_ret, o_lag, o_coef = oracle.cross_correlation(src, smp)
+    got = []
+    for batch in (1, 3, 40):
+        S = np.tile(src, (batch, 1)); T = np.tile(smp, (batch, 1))
+        k = batch - 1                                # the probe is the last pair; the others differ from it
+        for b in range(batch - 1):
+            T[b] *= np.float32(-0.5 - b)
+        with mod.Plan(n, batch, 0) as plan:
+            lag, coef, ret = plan.xcorr_batch_f32(S, T)
+        assert (int(ret[k]), int(lag[k])) == (o_ret, o_lag) == (0, delay)
+        assert abs(float(coef[k]) - o_coef) < COEF_TOL
+        got.append(float(coef[k]))
+    assert max(got) - min(got) < 1e-12, got
+
+
 @pytest.mark.parametrize("n", [7, 11, 49, 1001, 12347, 44100])
 def test_lengths_that_are_not_smooth(mod, n):
     """2N has a prime factor > 5: the transform is embedded in a longer smooth one"""
