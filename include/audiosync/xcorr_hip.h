@@ -75,20 +75,22 @@ void asx_plan_destroy(asx_plan *plan);
  * The transforms run in float32; every lag whose float32 value is within the float32 error bound of
  * the float32 maximum is re-evaluated exactly and the reference's rule is applied to the exact values,
  * for up to asx_plan_peak_capacity() such lags per pair (2048..16384 by sample_len; all 2N lags for
- * short tracks).  A pair with more near-ties than that (an all-zero correlation, or a signal periodic
- * in that many lags) is counted -- asx_plan_peak_overflows(): *count = number of such pairs since the
- * plan was created -- and
- *   - the SYNCHRONOUS entry points (asx_xcorr_f64 = cross_correlation(double*), asx_xcorr_batch_f32,
- *     asx_xcorr_batch_multi, asx_stream_xcorr) take a second look at it with lists that hold all 2N
- *     lags, so that no candidate limit remains (asx_plan_peak_repairs() counts these; slow: candidates
- *     x N multiply-adds);
- *   - the asynchronous device-resident batch (asx_xcorr_batch_f32_dev) keeps the float32 argmax, which
- *     already is the smallest lag among equal float32 values.
+ * short tracks).  A pair with more near-ties than that (a signal periodic in that many lags, an offset
+ * of hundreds of deviations in both tracks) is marked on the device, counted -- asx_plan_peak_overflows():
+ * *count = number of such pairs since the plan was created -- and EVERY entry point, the device-resident
+ * asx_xcorr_batch_f32_dev included, takes a second look at it before it returns: the pair's transforms
+ * again on the mean-removed source, into lists that hold all 2N lags, so that no candidate limit remains
+ * and the lag is the reference's float64 argmax by construction (asx_plan_peak_repairs() counts these;
+ * slow: candidates x N multiply-adds).  The price: one host synchronisation of the call's stream per call
+ * (per window of >= 1024 pairs of a very long batch), behind the last launch group; the second look itself
+ * only runs when the list of marked pairs is not empty.
+ * asx_plan_set_exact(plan, 0) trades that for a fully asynchronous asx_xcorr_batch_f32_dev: no host
+ * synchronisation, and a marked pair comes back with ret[i] = 1 ("inexact: lag[i] is the float32 argmax,
+ * submit the pair again on an exact plan") -- never silently.  ret[i] = 1 cannot occur in the default mode.
  * Both getters synchronise the plan's streams. */
 int asx_plan_peak_overflows(asx_plan *plan, uint64_t *count);
 int asx_plan_peak_repairs(asx_plan *plan, uint64_t *count);
-/* on != 0: asx_xcorr_batch_f32_dev also takes the second look (it then synchronises with the host once
- * per launch group, which costs about 1 % of the throughput); default off. */
+/* on != 0 (the default): see above.  Synchronises the plan's streams. */
 int asx_plan_set_exact(asx_plan *plan, int on);
 size_t asx_plan_peak_capacity(const asx_plan *plan);
 
@@ -118,8 +120,10 @@ int asx_xcorr_batch_f32(asx_plan *plan, const float *source, const float *sample
 
 /* Same with everything already resident in this plan's device memory space.
  * All pointers are DEVICE pointers; `stream` is a hipStream_t (NULL = the
- * plan's own stream).  Asynchronous: results are valid after the stream is
- * synchronised.  source pairs are 2N floats apart, sample pairs N floats.
+ * plan's own stream).  Results are valid after the stream is synchronised (the
+ * call itself waits once for its kernels to look at the list of overflowed pairs,
+ * see asx_plan_set_exact; what it enqueues after that is asynchronous).
+ * source pairs are 2N floats apart, sample pairs N floats.
  * A plan's workspaces are shared by all its calls: use ONE stream at a time per plan
  * (calls on different streams must be ordered by the caller, e.g. with events);
  * concurrent work belongs on separate plans. */

@@ -107,7 +107,7 @@ struct asx_plan {
     } lanes[2];
     int nlanes = 1;   // ASX_LANES=2 enables the second lane (measured: +0..4 %)
     hipEvent_t fork = nullptr;
-    // Second look for pairs whose near-tie list overflowed (lazy; see repair_overflows): lists that hold
+    // Second look for pairs whose near-tie list overflowed (lazy; see second_look): lists that hold
     // every lag of ONE pair
     struct BigPeak {
         AsxCand *cand = nullptr;
@@ -118,9 +118,12 @@ struct asx_plan {
         double *stats = nullptr;     // {mean of source, sum of sample, their product = the shift of r}
         size_t cap = 0;
     } big;
-    std::vector<uint32_t> h_cand_n;
+    // pairs whose near-tie list overflowed since the list was last emptied (k_finalize appends, resolve_overflows reads)
+    uint32_t *over_list = nullptr, *over_n = nullptr;
+    size_t over_cap = 0;
+    std::vector<uint32_t> h_over;
     unsigned long long repaired = 0;   // pairs that took the second look
-    bool exact_async = false;          // asx_plan_set_exact: the device-resident batch also takes the second look
+    bool exact = true;                 // asx_plan_set_exact: every entry point takes the second look (default)
     // staging for the host-pointer entry points (lazy)
     float *st_src = nullptr, *st_smp = nullptr;
     int64_t *st_lag = nullptr;
@@ -210,7 +213,9 @@ static int plan_init(asx_plan *p, size_t N, size_t max_batch, const char *split)
     for (int l = 0; l < p->nlanes; l++) {
         asx_plan::Lane &ln = p->lanes[l];
         ln.pk.cap = (uint32_t)cap;
-        if (dev_alloc(p, &ln.zxa, g * h.M) || dev_alloc(p, &ln.zya, g * h.M) || dev_alloc(p, &ln.ga, g * h.M) ||
+        // (M1 + 1) rows per pair and spectrum: the real-column kernels (rlayout.hip) keep rows k1 = 0 .. M1
+        const size_t mz = ((size_t)h.M1 + 1) * (size_t)h.M2;
+        if (dev_alloc(p, &ln.zxa, g * mz) || dev_alloc(p, &ln.zya, g * mz) || dev_alloc(p, &ln.ga, g * mz) ||
             dev_alloc(p, &ln.pk.nrm_part, g * 2 * (size_t)h.ntiles) || dev_alloc(p, &ln.pk.bound2, g) ||
             dev_alloc(p, &ln.pk.pairmax, g) || dev_alloc(p, &ln.pk.cand_n, g) ||
             dev_alloc(p, &ln.pk.cand, g * cap) || dev_alloc(p, &ln.pk.refine_n, g) ||
@@ -221,6 +226,16 @@ static int plan_init(asx_plan *p, size_t N, size_t max_batch, const char *split)
         HIP_TRY(hipMemset(ln.pk.overflows, 0, sizeof(unsigned long long)));
         HIP_TRY(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&ln.done, hipEventDisableTiming));
+    }
+    // the list of overflowed pairs is one per plan (the lanes append with atomics); a "window" of a device-resident
+    // batch between two looks at it never holds more pairs than this
+    p->over_cap = std::max<size_t>(g * (size_t)p->nlanes, 1024);
+    if (dev_alloc(p, &p->over_list, p->over_cap) || dev_alloc(p, &p->over_n, 1)) return -1;
+    HIP_TRY(hipMemset(p->over_n, 0, sizeof(uint32_t)));
+    for (int l = 0; l < p->nlanes; l++) {
+        p->lanes[l].pk.over_list = p->over_list;
+        p->lanes[l].pk.over_n = p->over_n;
+        p->lanes[l].pk.over_cap = (uint32_t)p->over_cap;
     }
     HIP_TRY(hipEventCreateWithFlags(&p->fork, hipEventDisableTiming));
     d.stamps = nullptr;
@@ -404,7 +419,13 @@ extern "C" int asx_plan_set_exact(asx_plan *p, int on)
 {
     if (!p) return fail("asx_plan_set_exact: null argument");
     std::lock_guard<std::mutex> guard(p->lock);
-    p->exact_async = on != 0;
+    DevGuard dg(p->device);
+    if (!dg.ok) return fail("cannot select device %d", p->device);
+    // whatever the asynchronous mode left on the list belongs to calls that have returned: start empty
+    for (int l = 0; l < p->nlanes; l++) HIP_TRY(hipStreamSynchronize(p->lanes[l].stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    HIP_TRY(hipMemset(p->over_n, 0, sizeof(uint32_t)));
+    p->exact = on != 0;
     return 0;
 }
 
@@ -491,7 +512,7 @@ static int prof_mark(asx_plan *p, hipStream_t s, size_t slot)
 template <typename TIn>
 static int run_group(asx_plan *p, const float *d_src, const float *d_smp, const TIn *p_src,
                      const TIn *p_smp, size_t g, int64_t *d_lag, double *d_coef, int32_t *d_ret,
-                     float *d_r, hipStream_t s, size_t group_index, int lane = 0)
+                     float *d_r, hipStream_t s, size_t group_index, int lane = 0, uint32_t pair_base = 0)
 {
     const AsxDev &P = p->dev;
     asx_plan::Lane &W = p->lanes[lane];
@@ -503,7 +524,7 @@ static int run_group(asx_plan *p, const float *d_src, const float *d_smp, const 
     if (prof_mark(p, s, e0 + 2)) return -1;
     asx_launch_inv_cols(P, W.ga, W.pk, d_r, (int)g, s);
     if (prof_mark(p, s, e0 + 3)) return -1;
-    asx_launch_finalize(P, W.pk, W.seg, (int)g, s);
+    asx_launch_finalize(P, W.pk, W.seg, (int)g, s, pair_base);
     if (sizeof(TIn) == sizeof(float))
         asx_launch_refine_f32(P, (const float *)p_src, (const float *)p_smp, W.pk, W.seg, (int)g, s);
     else
@@ -520,82 +541,93 @@ static int run_group(asx_plan *p, const float *d_src, const float *d_smp, const 
     return 0;
 }
 
-// Second look at the pairs of the group just run whose near-tie list overflowed (more lags inside the
-// float32 error window than the per-pair list holds: a pure tone of low frequency at a production
-// length has hundreds of thousands).  For each such pair the inverse column pass is run again on its G
-// (still in the lane's workspace) into a list that holds all 2N lags, every listed lag is re-evaluated
-// exactly, and the Pearson pass is redone for the lag that wins: the reference's float64 scan
-// (src/cross_correlation.c:52-67) has no candidate limit, so neither has this path.  It costs
-// candidates x N double-double multiply-adds (about 0.2 s for 400 000 candidates at N = 1 440 000) and
-// needs the host to look at the group's counters, so only the synchronous entry points call it
-// (cross_correlation(double*), the host-array batch, the growing-window stream); the device-resident
-// asynchronous batch counts such pairs instead (asx_plan_peak_overflows).
-// Before that, the transforms of the pair are run again on (source - mean of source): an offset of hundreds of standard
-// deviations in BOTH tracks is what makes every lag a near-tie (the float32 error bound scales with both norms), and
-// r[k] = r'[k] + mean * sum(sample) exactly, a constant that k_inv_cols adds back when it forms the keys
-// (AsxPeakWs::shift, peak_key_shifted).  With the offset gone from the source's norm the window shrinks by the ratio
-// offset / deviation and the list that reaches the exact re-evaluation is short again.
+// Second look at the pairs whose near-tie list overflowed (more lags inside the float32 error window than the
+// per-pair list holds: a signal periodic in a few frames at a production length has hundreds of thousands of exactly
+// tied peaks; an offset of hundreds of deviations in BOTH tracks makes every lag a near-tie).  k_finalize put their
+// indices on the plan's list; every entry point reads it -- ONE host synchronisation per call (per window of
+// `over_cap` pairs in a long device-resident batch), the price of a lag that is the reference's float64 argmax by
+// construction (src/cross_correlation.c:52-67 has no candidate limit) -- and, only when the list is not empty, runs
+// each listed pair again:
+//   (i)  its transforms on (source - mean of source): the float32 error bound scales with both norms, and
+//        r[k] = r'[k] + mean * sum(sample) exactly, a constant that k_inv_cols adds back when it forms the keys
+//        (AsxPeakWs::shift, peak_key_shifted): with the offset gone from the source's norm the window shrinks by the
+//        ratio offset / deviation;
+//   (ii) into lists that hold all 2N lags; every listed lag is re-evaluated exactly (candidates x N double-double
+//        multiply-adds: about 0.2 s for 400 000 candidates at N = 1 440 000) and the Pearson pass is redone for the
+//        lag that wins.
+// It runs on `s` behind everything the call has launched (the lanes have been joined), in the workspace slot 0 of
+// lane 0 and the plan's one set of big lists: nothing else is in flight on this plan (one stream at a time per plan).
+// The pointers are the bases the list's indices count from: pair i of the list is f_src + i * 2N etc.
 template <typename TIn>
-static int repair_overflows(asx_plan *p, int lane, size_t g, const float *f_src, const float *f_smp, const TIn *p_src,
-                            const TIn *p_smp, int64_t *d_lag, double *d_coef, int32_t *d_ret, hipStream_t s)
+static int second_look(asx_plan *p, size_t i, const float *f_smp, const TIn *p_src, const TIn *p_smp, int64_t *d_lag,
+                       double *d_coef, int32_t *d_ret, hipStream_t s)
 {
-    (void)f_src;
     const AsxDev &P = p->dev;
-    asx_plan::Lane &W = p->lanes[lane];
+    asx_plan::Lane &W = p->lanes[0];
     const size_t N = p->host.N;
-    if (W.pk.cap >= 2 * N) return 0; // the ordinary list already holds every lag
-    p->h_cand_n.resize(g);
-    HIP_TRY(hipMemcpyAsync(p->h_cand_n.data(), W.pk.cand_n, g * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    for (size_t i = 0; i < g; i++) {
-        if (p->h_cand_n[i] <= W.pk.cap) continue;
-        asx_plan::BigPeak &B = p->big;
-        if (!B.cand) {
-            // into a local first: a failed allocation must not leave half a set behind for the next call
-            // (what was allocated stays on the plan's list and is freed with the plan)
-            asx_plan::BigPeak T;
-            T.cap = 2 * N;
-            if (dev_alloc(p, &T.cand, T.cap) || dev_alloc(p, &T.refine_idx, T.cap) || dev_alloc(p, &T.refine_val, T.cap) ||
-                dev_alloc(p, &T.cand_n, 1) || dev_alloc(p, &T.refine_n, 1) || dev_alloc(p, &T.overflows, 1) ||
-                dev_alloc(p, &T.src_dc, 2 * N) || dev_alloc(p, &T.stats, 3))
-                return -1;
-            HIP_TRY(hipMemsetAsync(T.overflows, 0, sizeof(unsigned long long), s));
-            B = T;
-        }
-        AsxPeakWs K = W.pk;               // the pair's own norms, bound and (final) float32 maximum ...
-        K.nrm_part += i * 2 * (size_t)P.ntiles;
-        K.bound2 += i;
-        K.pairmax += i;
-        K.cand_n = B.cand_n; K.cand = B.cand; // ... with lists for all 2N lags
-        K.refine_n = B.refine_n; K.refine_idx = B.refine_idx; K.refine_val = B.refine_val;
-        K.overflows = B.overflows;
-        K.cap = (uint32_t)B.cap;
-        HIP_TRY(hipMemsetAsync(B.cand_n, 0, sizeof(uint32_t), s));
-        // the pair's transforms again, on the source minus its mean (k_rows recomputes the bound from the new norms
-        // and zeroes the pair's running maximum and count); r = r' + stats[2]
-        if (sizeof(TIn) == sizeof(float))
-            asx_launch_dc_remove_f32((const float *)p_src + i * 2 * N, (const float *)p_smp + i * N, P.N, (double)P.F, B.stats, B.src_dc, s);
-        else
-            asx_launch_dc_remove_f64((const double *)p_src + i * 2 * N, (const double *)p_smp + i * N, P.N, (double)P.F, B.stats, B.src_dc, s);
-        K.shift = B.stats + 2;
-        asx_launch_fwd_cols(P, B.src_dc, f_smp + i * N, W.zxa + i * (size_t)P.M, W.zya + i * (size_t)P.M, K, 1, s);
-        asx_launch_rows(P, W.zxa + i * (size_t)P.M, W.zya + i * (size_t)P.M, W.ga + i * (size_t)P.M, K, 1, s);
-        asx_launch_inv_cols(P, W.ga + i * (size_t)P.M, K, nullptr, 1, s);
-        asx_launch_finalize(P, K, W.seg + i, 1, s);
-        if (sizeof(TIn) == sizeof(float))
-            asx_launch_refine_f32(P, (const float *)p_src + i * 2 * N, (const float *)p_smp + i * N, K, W.seg + i, 1, s, 2048);
-        else
-            asx_launch_refine_f64(P, (const double *)p_src + i * 2 * N, (const double *)p_smp + i * N, K, W.seg + i, 1, s, 2048);
-        double *ps = W.psums + i * ASX_PEARSON_BLOCKS * 6;
-        if (sizeof(TIn) == sizeof(float))
-            asx_launch_pearson_f32((const float *)p_src + i * 2 * N, (const float *)p_smp + i * N, 2 * N, N, P.N,
-                                   W.seg + i, ps, ASX_PEARSON_BLOCKS, d_lag ? d_lag + i : nullptr, d_coef + i, d_ret ? d_ret + i : nullptr, 1, s);
-        else
-            asx_launch_pearson_f64((const double *)p_src + i * 2 * N, (const double *)p_smp + i * N, 2 * N, N, P.N,
-                                   W.seg + i, ps, ASX_PEARSON_BLOCKS, d_lag ? d_lag + i : nullptr, d_coef + i, d_ret ? d_ret + i : nullptr, 1, s);
-        HIP_TRY(hipGetLastError());
-        p->repaired++;
+    asx_plan::BigPeak &B = p->big;
+    if (!B.cand) {
+        // into a local first: a failed allocation must not leave half a set behind for the next call
+        // (what was allocated stays on the plan's list and is freed with the plan)
+        asx_plan::BigPeak T;
+        T.cap = 2 * N;
+        if (dev_alloc(p, &T.cand, T.cap) || dev_alloc(p, &T.refine_idx, T.cap) || dev_alloc(p, &T.refine_val, T.cap) ||
+            dev_alloc(p, &T.cand_n, 1) || dev_alloc(p, &T.refine_n, 1) || dev_alloc(p, &T.overflows, 1) ||
+            dev_alloc(p, &T.src_dc, 2 * N) || dev_alloc(p, &T.stats, 3))
+            return -1;
+        HIP_TRY(hipMemsetAsync(T.overflows, 0, sizeof(unsigned long long), s));
+        B = T;
     }
+    AsxPeakWs K = W.pk;                   // slot 0's norms, bound and running maximum (k_rows recomputes all three) ...
+    K.cand_n = B.cand_n; K.cand = B.cand; // ... with lists for all 2N lags: this look cannot overflow
+    K.refine_n = B.refine_n; K.refine_idx = B.refine_idx; K.refine_val = B.refine_val;
+    K.overflows = B.overflows;
+    K.over_list = nullptr; K.over_n = nullptr; K.over_cap = 0;
+    K.cap = (uint32_t)B.cap;
+    HIP_TRY(hipMemsetAsync(B.cand_n, 0, sizeof(uint32_t), s));
+    // r = r' + stats[2]
+    if (sizeof(TIn) == sizeof(float))
+        asx_launch_dc_remove_f32((const float *)p_src + i * 2 * N, (const float *)p_smp + i * N, P.N, (double)P.F, B.stats, B.src_dc, s);
+    else
+        asx_launch_dc_remove_f64((const double *)p_src + i * 2 * N, (const double *)p_smp + i * N, P.N, (double)P.F, B.stats, B.src_dc, s);
+    K.shift = B.stats + 2;
+    asx_launch_fwd_cols(P, B.src_dc, f_smp + i * N, W.zxa, W.zya, K, 1, s);
+    asx_launch_rows(P, W.zxa, W.zya, W.ga, K, 1, s);
+    asx_launch_inv_cols(P, W.ga, K, nullptr, 1, s);
+    asx_launch_finalize(P, K, W.seg, 1, s);
+    if (sizeof(TIn) == sizeof(float))
+        asx_launch_refine_f32(P, (const float *)p_src + i * 2 * N, (const float *)p_smp + i * N, K, W.seg, 1, s, 2048);
+    else
+        asx_launch_refine_f64(P, (const double *)p_src + i * 2 * N, (const double *)p_smp + i * N, K, W.seg, 1, s, 2048);
+    // (the partial-block count of this one-pair launch differs from the batch's: the last bits of the coefficient
+    //  depend on the merge tree, see the numeric contract in DESIGN.md)
+    if (sizeof(TIn) == sizeof(float))
+        asx_launch_pearson_f32((const float *)p_src + i * 2 * N, (const float *)p_smp + i * N, 2 * N, N, P.N,
+                               W.seg, W.psums, ASX_PEARSON_BLOCKS, d_lag ? d_lag + i : nullptr, d_coef + i, d_ret ? d_ret + i : nullptr, 1, s);
+    else
+        asx_launch_pearson_f64((const double *)p_src + i * 2 * N, (const double *)p_smp + i * N, 2 * N, N, P.N,
+                               W.seg, W.psums, ASX_PEARSON_BLOCKS, d_lag ? d_lag + i : nullptr, d_coef + i, d_ret ? d_ret + i : nullptr, 1, s);
+    HIP_TRY(hipGetLastError());
+    p->repaired++;
+    return 0;
+}
+
+template <typename TIn>
+static int resolve_overflows(asx_plan *p, const float *f_smp, const TIn *p_src, const TIn *p_smp, int64_t *d_lag,
+                             double *d_coef, int32_t *d_ret, hipStream_t s)
+{
+    if (p->lanes[0].pk.cap >= 2 * p->host.N) return 0; // the ordinary list already holds every lag
+    uint32_t n = 0;
+    HIP_TRY(hipMemcpyAsync(&n, p->over_n, sizeof(n), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (n == 0) return 0;
+    if (n > p->over_cap) return fail("internal: %u overflowed pairs in a window of %zu", n, p->over_cap);
+    p->h_over.resize(n);
+    HIP_TRY(hipMemcpyAsync(p->h_over.data(), p->over_list, n * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemsetAsync(p->over_n, 0, sizeof(uint32_t), s));
+    HIP_TRY(hipStreamSynchronize(s));
+    for (uint32_t k = 0; k < n; k++)
+        if (second_look<TIn>(p, p->h_over[k], f_smp, p_src, p_smp, d_lag, d_coef, d_ret, s)) return -1;
     return 0;
 }
 
@@ -615,32 +647,36 @@ extern "C" int asx_xcorr_batch_f32_dev(asx_plan *p, const float *d_source, const
     const bool overlap = (p->nlanes == 2) && !p->profiling && batch >= 8;
     size_t chunk = p->group;
     if (overlap && batch < 2 * chunk) chunk = (batch + 1) / 2;
-    if (overlap) {
-        HIP_TRY(hipEventRecord(p->fork, s));
-        for (int l = 0; l < 2; l++) HIP_TRY(hipStreamWaitEvent(p->lanes[l].stream, p->fork, 0));
-    }
+    // windows: the pairs between two looks at the list of overflowed pairs (asx_plan_set_exact, on by default); a
+    // window is a whole number of chunks and at most `over_cap` pairs, i.e. the whole batch unless it is very long
+    const size_t window = p->exact ? std::max<size_t>(chunk, p->over_cap / chunk * chunk) : batch;
     size_t gi = 0;
-    for (size_t done = 0; done < batch; done += chunk, gi++) {
-        const size_t g = std::min(chunk, batch - done);
-        const int lane = overlap ? (int)(gi & 1) : 0;
-        hipStream_t ls = overlap ? p->lanes[lane].stream : s;
-        if (run_group<float>(p, d_source + done * 2 * N, d_sample + done * N, d_source + done * 2 * N,
-                             d_sample + done * N, g, d_lag ? d_lag + done : nullptr, d_coef + done,
-                             d_ret ? d_ret + done : nullptr, nullptr, ls, gi, lane))
-            return -1;
-        // asx_plan_set_exact: look at the group's counters (one host synchronisation per group) and take the
-        // second look at pairs whose near-tie list overflowed, before the next group reuses the workspaces
-        if (p->exact_async &&
-            repair_overflows<float>(p, lane, g, d_source + done * 2 * N, d_sample + done * N, d_source + done * 2 * N,
-                                    d_sample + done * N, d_lag ? d_lag + done : nullptr, d_coef + done,
-                                    d_ret ? d_ret + done : nullptr, ls))
-            return -1;
-    }
-    if (overlap) {
-        for (int l = 0; l < 2; l++) {
-            HIP_TRY(hipEventRecord(p->lanes[l].done, p->lanes[l].stream));
-            HIP_TRY(hipStreamWaitEvent(s, p->lanes[l].done, 0));
+    for (size_t w0 = 0; w0 < batch; w0 += window) {
+        const size_t wn = std::min(window, batch - w0);
+        if (overlap) {
+            HIP_TRY(hipEventRecord(p->fork, s));
+            for (int l = 0; l < 2; l++) HIP_TRY(hipStreamWaitEvent(p->lanes[l].stream, p->fork, 0));
         }
+        for (size_t done = w0; done < w0 + wn; done += chunk, gi++) {
+            const size_t g = std::min(chunk, w0 + wn - done);
+            const int lane = overlap ? (int)(gi & 1) : 0;
+            hipStream_t ls = overlap ? p->lanes[lane].stream : s;
+            if (run_group<float>(p, d_source + done * 2 * N, d_sample + done * N, d_source + done * 2 * N,
+                                 d_sample + done * N, g, d_lag ? d_lag + done : nullptr, d_coef + done,
+                                 d_ret ? d_ret + done : nullptr, nullptr, ls, gi, lane, (uint32_t)(done - w0)))
+                return -1;
+        }
+        if (overlap) {
+            for (int l = 0; l < 2; l++) {
+                HIP_TRY(hipEventRecord(p->lanes[l].done, p->lanes[l].stream));
+                HIP_TRY(hipStreamWaitEvent(s, p->lanes[l].done, 0));
+            }
+        }
+        // the second look, behind the window's last group (one host synchronisation per window)
+        if (p->exact &&
+            resolve_overflows<float>(p, d_sample + w0 * N, d_source + w0 * 2 * N, d_sample + w0 * N,
+                                     d_lag ? d_lag + w0 : nullptr, d_coef + w0, d_ret ? d_ret + w0 : nullptr, s))
+            return -1;
     }
     prof_end_call(p, gi);
     return 0;
@@ -689,7 +725,7 @@ extern "C" int asx_xcorr_batch_f32(asx_plan *p, const float *source, const float
         if (run_group<float>(p, p->st_src, p->st_smp, p->st_src, p->st_smp, g, p->st_lag, p->st_coef,
                              p->st_ret, nullptr, s, 0))
             return -1;
-        if (repair_overflows<float>(p, 0, g, p->st_src, p->st_smp, p->st_src, p->st_smp, p->st_lag, p->st_coef, p->st_ret, s)) return -1;
+        if (resolve_overflows<float>(p, p->st_smp, p->st_src, p->st_smp, p->st_lag, p->st_coef, p->st_ret, s)) return -1;
         HIP_TRY(hipMemcpyAsync(lag + done, p->st_lag, g * sizeof(int64_t), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipMemcpyAsync(coef + done, p->st_coef, g * sizeof(double), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipMemcpyAsync(ret + done, p->st_ret, g * sizeof(int32_t), hipMemcpyDeviceToHost, s));
@@ -920,7 +956,7 @@ extern "C" int asx_xcorr_f64(asx_plan *p, const double *source, const double *sa
     if (run_group<double>(p, p->st_src, p->st_smp, p->st_src64, p->st_smp64, 1, p->st_lag, p->st_coef,
                           p->st_ret, nullptr, s, 0))
         return -1;
-    if (repair_overflows<double>(p, 0, 1, p->st_src, p->st_smp, p->st_src64, p->st_smp64, p->st_lag, p->st_coef, p->st_ret, s)) return -1;
+    if (resolve_overflows<double>(p, p->st_smp, p->st_src64, p->st_smp64, p->st_lag, p->st_coef, p->st_ret, s)) return -1;
     int64_t h_lag = 0;
     double h_coef = 0;
     int32_t h_ret = -1;
@@ -1142,7 +1178,7 @@ extern "C" int asx_stream_xcorr(asx_stream *st, size_t sample_len, long *lag, do
     if (run_group<double>(p, st->src32, st->smp32, st->src64, st->smp64, 1, st->d_lag, st->d_coef, st->d_ret,
                           nullptr, s, 0))
         return -1;
-    if (repair_overflows<double>(p, 0, 1, st->src32, st->smp32, st->src64, st->smp64, st->d_lag, st->d_coef, st->d_ret, s)) return -1;
+    if (resolve_overflows<double>(p, st->smp32, st->src64, st->smp64, st->d_lag, st->d_coef, st->d_ret, s)) return -1;
     int64_t h_lag = 0;
     double h_coef = 0;
     int32_t h_ret = -1;

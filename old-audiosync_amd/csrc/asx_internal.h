@@ -90,7 +90,9 @@ struct AsxSeg {           // per pair, produced by k_finalize
     uint32_t smp_off;     // first sample frame
     uint32_t len;         // segment length (N, or N-|lag|; may be 0)
     uint32_t peak;        // raw argmax index in [0, 2N)
+    uint32_t flags;       // ASX_SEG_INEXACT: the pair's near-tie list overflowed, `peak` is the float32 argmax (to be looked at again)
 };
+#define ASX_SEG_INEXACT 1u
 
 // kernel launchers (defined in xcorr_kernels.hip, called from asx_api.hip)
 struct AsxCand {          // one near-maximum lag found by a column tile
@@ -108,9 +110,12 @@ struct AsxPeakWs {
     uint32_t *refine_n;    // [pairs] lags to re-evaluate (0 = the float32 argmax stands)
     uint32_t *refine_idx;  // [pairs][cap]
     double *refine_val;    // [pairs][cap] exact r[idx]
-    unsigned long long *overflows; // [1] pairs whose candidate list did not fit (float32 argmax kept), cumulative
+    unsigned long long *overflows; // [1] pairs whose candidate list did not fit, cumulative
+    uint32_t *over_list;   // [over_cap] or null: indices (pair_base + pair) of those pairs since the list was last emptied --
+    uint32_t *over_n;      // [1] ... and their number: what the entry points read to take the second look (asx_api.hip)
+    uint32_t over_cap;
     const double *shift;   // [pairs] or null: c with r[k] = (what the transforms deliver) + c for every k -- the second look at a pair
-                           // runs the transforms on (source - mean), see repair_overflows; null / 0 everywhere else
+                           // runs the transforms on (source - mean), see second_look (asx_api.hip); null / 0 everywhere else
     uint32_t cap;          // candidate capacity per pair
 };
 
@@ -122,7 +127,10 @@ void asx_launch_inv_cols(const AsxDev &P, const float2 *ga, const AsxPeakWs &W, 
                          int npairs, hipStream_t s);
 bool asx_launch_rows2(const AsxDev &P, const float2 *zxa, const float2 *zya, float2 *ga, const AsxPeakWs &W,
                       int npairs, hipStream_t s); // rows2.hip; false = no two-pass kernel for this row length
-void asx_launch_finalize(const AsxDev &P, const AsxPeakWs &W, AsxSeg *seg, int npairs, hipStream_t s);
+// rlayout.hip: the real-column decomposition (production lengths); false = no kernel compiled in for this plan
+bool asx_launch_rows_r(const AsxDev &P, const float2 *cx, const float2 *cy, float2 *q, const AsxPeakWs &W, int npairs,
+                       hipStream_t s);
+void asx_launch_finalize(const AsxDev &P, const AsxPeakWs &W, AsxSeg *seg, int npairs, hipStream_t s, uint32_t pair_base = 0);
 void asx_launch_refine_f32(const AsxDev &P, const float *src, const float *smp, const AsxPeakWs &W,
                            AsxSeg *seg, int npairs, hipStream_t s, int dot_blocks = ASX_DOT_BLOCKS);
 void asx_launch_refine_f64(const AsxDev &P, const double *src, const double *smp, const AsxPeakWs &W,

@@ -578,7 +578,7 @@ __device__ __forceinline__ float peak_key_of(float value, uint32_t idx)
     return idx == 0u ? z : a;
 }
 // The same when the transforms ran on (source - mean) (second look at a pair with a large offset in both tracks,
-// repair_overflows): r[k] = value + c with c = mean * sum(sample), the same for every k.  Keys are taken RELATIVE to
+// second_look, asx_api.hip): r[k] = value + c with c = mean * sum(sample), the same for every k.  Keys are taken RELATIVE to
 // |c| -- key' = |r| - |c|, lag 0: r - |c| -- so that float32 keeps the differences between lags when |c| >> |value|;
 // a common shift changes neither the order of the keys nor the width of the near-maximum window.
 __device__ __forceinline__ float peak_key_shifted(float value, uint32_t idx, double c)
@@ -691,7 +691,7 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_inv_cols(const AsxDe
     // maximum 0 inside a window of width 0, the lists would overflow and the synchronous entry points would
     // re-evaluate all of them exactly (seconds at N = 1 440 000).  Block-uniform; r_out (tests) still wants zeros.
     if (W.bound2[pair] == 0.f && r_out == nullptr) return;
-    const double shift = W.shift ? W.shift[pair] : 0.0; // block-uniform; non-zero only in the second look (repair_overflows)
+    const double shift = W.shift ? W.shift[pair] : 0.0; // block-uniform; non-zero only in the second look (second_look, asx_api.hip)
     const int logH = logT - 1, H = T >> 1, M2 = P.M2;
     const int c0 = tile * T;
     const float2 *in = ga + pair * (size_t)P.M;
@@ -1001,6 +1001,7 @@ __device__ __forceinline__ AsxSeg make_seg(uint32_t peak, uint32_t N)
 {
     AsxSeg s;
     s.peak = peak;
+    s.flags = 0;
     if (peak >= N) {
         // src/cross_correlation.c:256-263: lag = (lag % N) - N; source[0 .. N+lag), sample[-lag .. N)
         const long long l = (long long)(peak % N) - (long long)N;
@@ -1018,7 +1019,8 @@ __device__ __forceinline__ AsxSeg make_seg(uint32_t peak, uint32_t N)
     return s;
 }
 
-__global__ __launch_bounds__(ASX_THREADS) void k_finalize(const AsxDev *__restrict__ Pp, AsxPeakWs W, AsxSeg *__restrict__ seg)
+__global__ __launch_bounds__(ASX_THREADS) void k_finalize(const AsxDev *__restrict__ Pp, AsxPeakWs W, AsxSeg *__restrict__ seg,
+                                                           uint32_t pair_base)
 {
     const uint32_t N = Pp->N;
     __shared__ uint32_t nsel;
@@ -1038,13 +1040,23 @@ __global__ __launch_bounds__(ASX_THREADS) void k_finalize(const AsxDev *__restri
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        seg[pair] = make_seg(best ? peak_index(best) : 0u, N);
-        // One candidate: the float32 argmax is unambiguous.  More than the list holds (r == 0
-        // everywhere, or a signal periodic in more than `cap` lags): the float32 result stands, which
-        // already follows the smallest-index rule, and the event is counted (asx_plan_peak_overflows).
+        AsxSeg sg = make_seg(best ? peak_index(best) : 0u, N);
+        // One candidate: the float32 argmax is unambiguous.  More than the list holds (a signal periodic in
+        // more than `cap` lags, an offset of hundreds of deviations in both tracks): the float32 argmax is only a
+        // placeholder.  The pair is MARKED (its ret becomes ASX_RET_INEXACT in k_pearson_final), counted
+        // (asx_plan_peak_overflows) and put on the list the entry points read to take the second look
+        // (asx_api.hip: resolve_overflows): the reference's scan has no candidate limit (src/cross_correlation.c:52-67).
         const bool over = ntot > W.cap;
+        if (over) sg.flags = ASX_SEG_INEXACT;
+        seg[pair] = sg;
         W.refine_n[pair] = (!over && nsel >= 2u) ? nsel : 0u;
-        if (over) atomicAdd(W.overflows, 1ull);
+        if (over) {
+            atomicAdd(W.overflows, 1ull);
+            if (W.over_list) {
+                const uint32_t slot = atomicAdd(W.over_n, 1u);
+                if (slot < W.over_cap) W.over_list[slot] = pair_base + (uint32_t)pair;
+            }
+        }
     }
 }
 
@@ -1307,7 +1319,9 @@ __global__ __launch_bounds__(64) void k_pearson_final(const AsxSeg *__restrict__
         if (lag) lag[pair] = s.lag;
         coef[pair] = c;
         // src/cross_correlation.c:276: NaN coefficient -> return -1 (outputs already written)
-        if (ret) ret[pair] = (c != c) ? -1 : 0;
+        // ... unless the lag itself is still the float32 placeholder of an overflowed pair: 1 = "inexact, look again"
+        // (only ever visible to callers of the asynchronous mode, include/audiosync/xcorr_hip.h)
+        if (ret) ret[pair] = (s.flags & ASX_SEG_INEXACT) ? 1 : (c != c) ? -1 : 0;
     }
 }
 
@@ -1329,7 +1343,7 @@ __global__ __launch_bounds__(ASX_THREADS) void k_results_to_ms(const int64_t *__
 }
 
 // ---------------------------------------------------------------------------
-// second look, DC removal (repair_overflows): one pair, one block each.  An offset of hundreds of standard deviations
+// second look, DC removal (second_look, asx_api.hip): one pair, one block each.  An offset of hundreds of standard deviations
 // in BOTH tracks makes the float32 error bound (proportional to |source|_2 |sample|_2) wider than the whole range of
 // r, every lag a near-tie.  r'[k] = sum (source[n+k] - m) sample[n] = r[k] - m * sum(sample) for ANY constant m: the
 // transforms then run on a zero-mean source, whose norm no longer carries the offset, and the constant goes back in
@@ -1607,6 +1621,8 @@ void asx_launch_rows(const AsxDev &P, const float2 *zxa, const float2 *zya, floa
                      const AsxPeakWs &W, int npairs, hipStream_t s)
 {
     if (!generic_only() && asx_launch_rows2(P, zxa, zya, ga, W, npairs, s)) return; // two LDS passes per transform
+    static const bool time_r = getenv("ASX_TIME_ROWS_R") != nullptr; // timing probe: right traffic, meaningless results
+    if (time_r && asx_launch_rows_r(P, zxa, zya, ga, W, npairs, s)) return;
     if (generic_only() || !asx_launch_rows_static(P, zxa, zya, ga, W, npairs, s))
         asx_launch_rows_generic(P, zxa, zya, ga, W, npairs, s);
 }
@@ -1618,9 +1634,9 @@ void asx_launch_inv_cols(const AsxDev &P, const float2 *ga, const AsxPeakWs &W, 
         asx_launch_inv_cols_generic(P, ga, W, r_out, npairs, s);
 }
 
-void asx_launch_finalize(const AsxDev &P, const AsxPeakWs &W, AsxSeg *seg, int npairs, hipStream_t s)
+void asx_launch_finalize(const AsxDev &P, const AsxPeakWs &W, AsxSeg *seg, int npairs, hipStream_t s, uint32_t pair_base)
 {
-    hipLaunchKernelGGL(k_finalize, dim3(npairs), dim3(ASX_THREADS), 0, s, P.self_dev, W, seg);
+    hipLaunchKernelGGL(k_finalize, dim3(npairs), dim3(ASX_THREADS), 0, s, P.self_dev, W, seg, pair_base);
 }
 
 void asx_launch_refine_f32(const AsxDev &P, const float *src, const float *smp, const AsxPeakWs &W,

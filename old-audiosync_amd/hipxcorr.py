@@ -406,12 +406,13 @@ class Plan:
         return c.value
 
     def set_exact(self, on=True):
-        """the asynchronous device batch also re-examines overflowing pairs (one host sync per launch group)"""
+        """on (the default): every entry point takes the second look at overflowing pairs (the device-resident batch waits
+        once per call for its kernels); off: that entry point stays asynchronous and marks such pairs with ret = 1"""
         if lib().asx_plan_set_exact(self._h, 1 if on else 0) != 0:
             raise AsxError(_err())
 
     def peak_repairs(self):
-        """overflowing pairs the synchronous entry points looked at again with lists for all 2N lags"""
+        """overflowing pairs that were looked at again with lists for all 2N lags"""
         c = ctypes.c_uint64(0)
         if lib().asx_plan_peak_repairs(self._h, ctypes.byref(c)) != 0:
             raise AsxError(_err())

@@ -155,8 +155,9 @@ def test_float32_error_stays_inside_the_bound(mod, n):
 
 
 def test_overflow_is_counted_and_looked_at_again(mod):
-    """the synchronous entry points re-run an overflowing pair with lists for all 2N lags: no candidate limit,
-    like the reference's scan (src/cross_correlation.c:52-67); the asynchronous device batch only counts"""
+    """EVERY entry point re-runs an overflowing pair with lists for all 2N lags: no candidate limit, like the
+    reference's scan (src/cross_correlation.c:52-67) -- the device-resident batch included, by default; with
+    asx_plan_set_exact(plan, 0) that entry point stays asynchronous and MARKS the pair (ret = 1) instead"""
     n = 48000
     with mod.Plan(n, 2, 0) as plan:
         cap = plan.peak_capacity
@@ -170,24 +171,67 @@ def test_overflow_is_counted_and_looked_at_again(mod):
         per = np.tile(base, 2 * n // 8)
         lag, coef, ret = plan.xcorr_batch_f32(np.stack([src, per]), np.stack([zero, per[:n]]))
         assert plan.peak_overflows() == 1 and plan.peak_repairs() == 1
-        # the device-resident asynchronous entry: counted, float32 argmax kept (smallest lag among equal keys)
+        # the device-resident entry point: the same second look, behind the batch's last group
         import torch
         d_src = torch.from_numpy(np.stack([src, per])).cuda(); d_smp = torch.from_numpy(np.stack([zero, per[:n]])).cuda()
-        d_lag = torch.zeros(2, dtype=torch.int64, device="cuda"); d_coef = torch.zeros(2, dtype=torch.float64, device="cuda")
-        d_ret = torch.zeros(2, dtype=torch.int32, device="cuda")
+        d_lag = torch.full((2,), -99, dtype=torch.int64, device="cuda"); d_coef = torch.zeros(2, dtype=torch.float64, device="cuda")
+        d_ret = torch.full((2,), 7, dtype=torch.int32, device="cuda")
         torch.cuda.synchronize()
         plan.xcorr_batch_dev(d_src.data_ptr(), d_smp.data_ptr(), 2, d_lag.data_ptr(), d_coef.data_ptr(), d_ret.data_ptr())
-        assert plan.peak_overflows() == 2 and plan.peak_repairs() == 1
-        assert int(d_lag[1]) % 8 == 0 and int(d_ret[0]) == -1
-        # ... unless the plan is told to (asx_plan_set_exact): then it synchronises per group and looks again
-        plan.set_exact(True)
+        assert plan.peak_overflows() == 2 and plan.peak_repairs() == 2
+        o_ret, o_lag, o_coef = oracle.cross_correlation(per, per[:n])
+        assert (o_ret, o_lag) == (0, 0)
+        assert int(d_lag[1]) == o_lag and int(d_ret[1]) == 0 and float(d_coef[1]) == 1.0
+        assert int(d_lag[0]) == 0 and int(d_ret[0]) == -1
+        # asynchronous mode: no second look, but never silently -- the pair comes back marked
+        plan.set_exact(False)
         d_lag.fill_(-99)
         plan.xcorr_batch_dev(d_src.data_ptr(), d_smp.data_ptr(), 2, d_lag.data_ptr(), d_coef.data_ptr(), d_ret.data_ptr())
         assert plan.peak_overflows() == 3 and plan.peak_repairs() == 2
-        assert int(d_lag[1]) == 0 and int(d_lag[0]) == 0 and int(d_ret[0]) == -1 and float(d_coef[1]) == 1.0
+        assert int(d_ret[1]) == 1 and int(d_lag[1]) % 8 == 0 and int(d_ret[0]) == -1
+        # ... and back: what the asynchronous call left on the list is not looked at by a later call
+        plan.set_exact(True)
+        plan.xcorr_batch_dev(d_src.data_ptr(), d_smp.data_ptr(), 1, d_lag.data_ptr(), d_coef.data_ptr(), d_ret.data_ptr())
+        assert plan.peak_overflows() == 3 and plan.peak_repairs() == 2
     assert int(ret[0]) == -1 and int(lag[0]) == 0          # like the reference: index 0, NaN coefficient
     # 12 000 exactly tied peaks (every 8th lag): the exact values tie, the smallest lag wins as in a sequential scan
     assert int(ret[1]) == 0 and int(lag[1]) == 0 and coef[1] == 1.0
+
+
+def test_overflowing_pairs_in_consecutive_groups_on_two_lanes(mod, monkeypatch):
+    """with two stream lanes the per-group second looks of round 3 shared one set of big lists.  The second
+    look now runs behind the joined lanes, once per call: overflowing pairs in consecutive groups (alternating lanes),
+    several per group, all come back as the float64 answer."""
+    import torch
+    monkeypatch.setenv("ASX_LANES", "2")
+    n = 24000
+    rng = np.random.default_rng(77)
+    batch, group = 16, 4
+    srcs, smps, want = [], [], []
+    for i in range(batch):
+        if i in (1, 5, 6, 11, 12):
+            period = 8 if i != 6 else 16
+            base = rng.integers(-5, 6, period).astype(np.float32)
+            s_ = np.tile(base, 2 * n // period)
+            t_ = np.roll(s_, -(i % period))[:n].copy()
+        else:
+            s_, t_, _ = oracle.synth_pair(9, i, n, 1)
+        srcs.append(s_); smps.append(t_)
+        want.append(oracle.cross_correlation(s_, t_))
+    with mod.Plan(n, group, 0) as plan:
+        assert plan.group == group and plan.peak_capacity < 2 * n
+        d_src = torch.from_numpy(np.stack(srcs)).cuda(); d_smp = torch.from_numpy(np.stack(smps)).cuda()
+        d_lag = torch.full((batch,), -99, dtype=torch.int64, device="cuda")
+        d_coef = torch.zeros(batch, dtype=torch.float64, device="cuda")
+        d_ret = torch.full((batch,), 7, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        plan.xcorr_batch_dev(d_src.data_ptr(), d_smp.data_ptr(), batch, d_lag.data_ptr(), d_coef.data_ptr(), d_ret.data_ptr())
+        plan.sync()
+        assert plan.peak_repairs() == 5
+    for i in range(batch):
+        o_ret, o_lag, o_coef = want[i]
+        assert (int(d_ret[i]), int(d_lag[i])) == (o_ret, o_lag), i
+        assert abs(float(d_coef[i]) - o_coef) < 1e-5, i
 
 
 def test_second_look_through_the_reference_api(hostlib):
@@ -290,7 +334,7 @@ def test_offset_in_both_tracks_takes_the_mean_removed_second_look(mod, hostlib, 
         dt = time.perf_counter() - t0
         assert (ret, lag) == (0, d) and abs(coef - o_coef) < COEF_TOL, (ratio, lag, d, coef, o_coef)
         assert dt < 0.5, (ratio, dt)
-        # the batched float32 entry points: host arrays (synchronous) and device-resident with asx_plan_set_exact
+        # the batched float32 entry point on host arrays
         with mod.Plan(n, 1, 0) as plan:
             lag_b, coef_b, ret_b = plan.xcorr_batch_f32(src32[None], smp32[None])
             assert (int(ret_b[0]), int(lag_b[0])) == (0, d) and abs(float(coef_b[0]) - o_coef) < COEF_TOL
