@@ -194,6 +194,20 @@ static int plan_init(asx_plan *p, size_t N, size_t max_batch, const char *split)
         dev_upload(p, &d.pos2_of_k2, h.pos2_of_k2) || dev_upload(p, &d.row_tasks, h.row_tasks))
         return -1;
 
+    // Which decomposition: the real-column kernels (rlayout.hip) when the plan allows them and they are compiled in for its
+    // schedules (the reference's six lengths); ASX_LAYOUT=packed forces the packed-sample kernels (A/B runs, the two-pass
+    // row kernel, the run-time-schedule kernels of ASX_GENERIC)
+    d.rlayout = 0;
+    d.col_pairs = nullptr;
+    d.col_tw = nullptr;
+    {
+        const char *lay = getenv("ASX_LAYOUT");
+        const bool packed = (lay && !strcmp(lay, "packed")) || getenv("ASX_GENERIC") || d.rows2_ra;
+        if (h.rlayout && !packed) {
+            if (dev_upload(p, &d.col_pairs, h.col_pairs) || dev_upload(p, &d.col_tw, h.col_tw)) return -1;
+            d.rlayout = asx_rlayout_available(d) ? 1 : 0;
+        }
+    }
     // group size: keep the three inter-kernel intermediates (24*M bytes per pair) of one
     // group around the size of the 256 MiB Infinity Cache so the next kernel re-reads them on die
     size_t ws_mb = 4096;

@@ -74,6 +74,9 @@ struct AsxDev {
     const int *pos1_of_k1; // k1 -> row slot
     const int *pos2_of_k2; // k2 -> slot inside a row after the forward row transform
     const int4 *row_tasks; // [M1/2+1] {slot of row k1, slot of row M1-k1, k1, M1-k1}: one load starts a k_rows block
+    int rlayout;           // 1: this plan runs the real-column kernels (rlayout.hip); 0: the packed-sample kernels (xcorr_kernels.hip)
+    const int4 *col_pairs; // real-column kernels (rlayout.hip): [M1/2 + 1] {u, slot of u, slot of M1 - u, 0}; null = not available
+    const float2 *col_tw;  // w_{2 M1}^u, same order
     const AsxDev *self_dev; // device copy of this struct (what the kernels read)
     unsigned long long *stamps; // diagnostic builds (-DASX_STAMPS) only: per-block phase clocks, 8 slots per block
     int stamp_kernel;      // which kernel records them: 0 k_rows, 1 k_fwd_cols, 2 k_inv_cols ($ASX_STAMPS = 1 | fwd | inv)
@@ -130,6 +133,10 @@ bool asx_launch_rows2(const AsxDev &P, const float2 *zxa, const float2 *zya, flo
 // rlayout.hip: the real-column decomposition (production lengths); false = no kernel compiled in for this plan
 bool asx_launch_rows_r(const AsxDev &P, const float2 *cx, const float2 *cy, float2 *q, const AsxPeakWs &W, int npairs,
                        hipStream_t s);
+bool asx_launch_fwd_cols_r(const AsxDev &P, const float *src, const float *smp, float2 *cx, float2 *cy, const AsxPeakWs &W,
+                           int npairs, hipStream_t s);
+bool asx_launch_inv_cols_r(const AsxDev &P, const float2 *q, const AsxPeakWs &W, float *r_out, int npairs, hipStream_t s);
+bool asx_rlayout_available(const AsxDev &P); // all three kernels compiled in for this plan's schedules
 void asx_launch_finalize(const AsxDev &P, const AsxPeakWs &W, AsxSeg *seg, int npairs, hipStream_t s, uint32_t pair_base = 0);
 void asx_launch_refine_f32(const AsxDev &P, const float *src, const float *smp, const AsxPeakWs &W,
                            AsxSeg *seg, int npairs, hipStream_t s, int dot_blocks = ASX_DOT_BLOCKS);

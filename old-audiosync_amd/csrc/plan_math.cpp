@@ -287,5 +287,22 @@ std::string asx_host_plan_build(size_t N, const char *split_override, AsxHostPla
         const int m1 = (M1 - k1) % M1;
         hp->row_tasks[k1] = make_int4(hp->pos1_of_k1[k1], hp->pos1_of_k1[m1], k1, m1);
     }
+    // The real-column kernels (rlayout.hip) untangle the column transforms inside the tile: frequencies u and M1 - u,
+    // u <= M1/2, pair up.  One entry per pair, {u, slot of u, slot of M1 - u}, ordered by the first slot so that
+    // consecutive lanes walk LDS (almost) slot by slot; col_tw = w_{2 M1}^u in the same order.
+    hp->col_pairs.clear();
+    hp->col_tw.clear();
+    hp->rlayout = false;
+    if (M1 % 2 == 0 && F == 2 * (uint64_t)N && M2 % T == 0 && T >= 4 && M2 % 4 == 0) {
+        std::vector<std::pair<int, int>> order; // (slot of u, u)
+        for (int u = 0; u <= M1 / 2; u++) order.push_back({ hp->pos1_of_k1[u], u });
+        std::sort(order.begin(), order.end());
+        for (const auto &o : order) {
+            const int u = o.second;
+            hp->col_pairs.push_back(make_int4(u, o.first, hp->pos1_of_k1[(M1 - u) % M1], 0));
+            hp->col_tw.push_back(unit_root((uint64_t)u, 2 * (uint64_t)M1));
+        }
+        hp->rlayout = true;
+    }
     return "";
 }

@@ -19,6 +19,10 @@ struct AsxHostPlan {
     int rows2_ra = 0, rows2_rb = 0; // its factors, M2 = RA*RB
     std::vector<int> k1_of_pos1, pos1_of_k1, pos2_of_k2;
     std::vector<int4> row_tasks;
+    // real-column decomposition (rlayout.hip): possible when M1 is even, the length is not embedded and tiles are whole
+    bool rlayout = false;
+    std::vector<int4> col_pairs;    // [M1/2 + 1] {u, slot of u, slot of M1 - u, 0}, ordered by the slot of u
+    std::vector<float2> col_tw;     // w_{2 M1}^u in the same order
 };
 
 // LDS budgets that bound the split (bytes per workgroup).

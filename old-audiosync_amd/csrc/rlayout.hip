@@ -62,35 +62,47 @@ __device__ __forceinline__ void wave_lds_sync()
 
 // ---------------------------------------------------------------------------
 // k_rows_r: grid ((M1 + 1) * npairs).  One block = row k1 of both spectra of one pair.
-//   S = Sched<M2, R0, R1, R2>: three DIF stages.  Stage 0 spans the row (block-wide, barrier after it); stages 1
-//   and 2 stay inside the R0 sub-blocks of length M2/R0 ("units"), and so do the first two stages of the inverse:
+//   S = Sched<n, R0, R1, R2>: three DIF stages.  Stage 0 spans the (sub-)row (block-wide, barrier after it); stages 1
+//   and 2 stay inside the R0 sub-blocks of length n/R0 ("units"), and so do the first two stages of the inverse:
 //   a wave that owns whole units runs  forward 1 -> forward 2 -> product -> inverse 2 -> inverse 1  on them with no
-//   block barrier in between.  Inverse stage 0 spans the row again; its outputs leave from registers.
+//   block barrier in between.  Inverse stage 0 spans the (sub-)row again.
+//   TWO = false: M2 = n, NT threads; the outputs of inverse stage 0 leave from registers.
+//   TWO = true:  M2 = 2n, 2*NT threads.  The first radix-2 DIF stage of the 2n-point row transforms runs in the
+//                registers of the load phase -- a[j] = c[j] + c[j+n], b[j] = (c[j] - c[j+n]) w_M2^j -- after which the
+//                even bins (from a) and the odd bins (from b) are two independent n-point problems: threads
+//                [0, NT) take a, threads [NT, 2NT) take b, each half in its own LDS region; they meet again in the
+//                store phase, Q[j] = A[j] + conj(w_M2^j) B[j], Q[j+n] = A[j] - conj(w_M2^j) B[j].  This is how the two
+//                longest reference lengths get 600- and 400-row column tiles of sixteen real columns (64-byte input
+//                pieces, whole 128-byte lines of C and Q) instead of 1200 / 800 rows of eight.
 // ---------------------------------------------------------------------------
-template <class S, int NT>
-__global__ __launch_bounds__(NT, ASX_ROWSR_WAVES) void k_rows_r(const AsxDev *__restrict__ Pp, const float2 *__restrict__ cx,
-                                                                 const float2 *__restrict__ cy, float2 *__restrict__ qo,
-                                                                 int nrows, size_t pair_pitch, AsxPeakWs W)
+template <class S, int NT, bool TWO>
+__global__ __launch_bounds__(TWO ? 2 * NT : NT, ASX_ROWSR_WAVES) void k_rows_r(const AsxDev *__restrict__ Pp, const float2 *__restrict__ cx,
+                                                                                const float2 *__restrict__ cy, float2 *__restrict__ qo,
+                                                                                int nrows, size_t pair_pitch, AsxPeakWs W)
 {
     static_assert(S::nstages == 3, "three-stage row schedules only");
-    constexpr int M2 = S::n;
+    constexpr int NS = S::n;                 // length of a (sub-)row transform
+    constexpr int M2 = TWO ? 2 * NS : NS;    // row length
+    constexpr int TWS = TWO ? 2 : 1;         // w_NS^q = tw2[TWS * q] (tw2 is the table of M2)
+    constexpr int NTB = TWO ? 2 * NT : NT;   // block size
     constexpr StageK K0 = S::stage(0), K1 = S::stage(1), K2 = S::stage(2);
     constexpr int R0 = K0.R, R1 = K1.R, R2 = K2.R;
     constexpr int Q0 = K0.q;  // butterflies of stage 0 = length of a unit
     constexpr int UN = K1.ns; // = Q0
     static_assert(UN == R1 * R2 && Q0 == UN && K2.q == 1, "unit = R1 x R2");
-    static_assert((M2 & 1) == 0, "rows move as 16 bytes per lane");
-    constexpr int HALF = M2 / 2, WSTEPS = (HALF + NT - 1) / NT;
+    static_assert((NS & 1) == 0, "rows move as 16 bytes per lane");
+    constexpr int HALF = NS / 2, WSTEPS = (HALF + NTB - 1) / NTB;
     constexpr int LPU = R1 > R2 ? R1 : R2, UPW = 64 / LPU, NW = NT / 64;
     static_assert(NT % 64 == 0 && UPW >= 1, "whole waves");
 
     const AsxDev &PD = *Pp;
     const AsxKP P = asx_kp(PD);
-    float4 *A4 = reinterpret_cast<float4 *>(asx_lds_r);
-    __shared__ float2 tw_step[WSTEPS]; // w_F^(k1 * 2*NT*i): the four-step twiddle from load step to load step
-    __shared__ float2 leg[R0];         // w_F^(k1 * Q0*t): ... and from leg to leg of the last inverse stage
-
     const int task = blockIdx.x, tid = threadIdx.x;
+    const int half = TWO ? tid / NT : 0, lt = tid - half * NT; // which sub-row, thread index inside its half
+    float4 *A4 = reinterpret_cast<float4 *>(asx_lds_r) + half * NS;
+    __shared__ float2 tw_step[WSTEPS]; // (1/2) w_F^(k1 * 2*NTB*i): the four-step twiddle from load step to load step
+    __shared__ float2 leg[R0];         // w_F^(k1 * Q0*t): ... and from leg to leg of the last inverse stage (!TWO)
+
     const int pair = task / nrows;
     const uint32_t k1 = (uint32_t)(task - pair * nrows);
     const size_t row = (size_t)pair * pair_pitch + (size_t)k1 * M2;
@@ -108,48 +120,71 @@ __global__ __launch_bounds__(NT, ASX_ROWSR_WAVES) void k_rows_r(const AsxDev *__
         }
     }
     // every row load of the thread first; the twiddle lookups below overlap them
-    float4 lx[WSTEPS], ly[WSTEPS];
+    float4 lx[WSTEPS], ly[WSTEPS], lx2[TWO ? WSTEPS : 1], ly2[TWO ? WSTEPS : 1];
     {
         const float2 *gx = cx + row, *gy = cy + row;
         static_for<0, WSTEPS>([&](auto I) __attribute__((always_inline)) {
-            const int q = tid + decltype(I)::value * NT;
+            const int q = tid + decltype(I)::value * NTB;
             if (q < HALF) {
                 lx[I] = *reinterpret_cast<const float4 *>(gx + 2 * q);
                 ly[I] = *reinterpret_cast<const float4 *>(gy + 2 * q);
+                if constexpr (TWO) {
+                    lx2[I] = *reinterpret_cast<const float4 *>(gx + NS + 2 * q);
+                    ly2[I] = *reinterpret_cast<const float4 *>(gy + NS + 2 * q);
+                }
             }
         });
     }
-    if (tid < WSTEPS) tw_step[tid] = tw_F(P, k1 * (uint32_t)(2 * NT * tid));
-    if (tid >= NT - R0) { const int t = tid - (NT - R0); leg[t] = tw_F(P, k1 * (uint32_t)(Q0 * t)); }
-    const float2 twa = tw_F(P, k1 * (uint32_t)(2 * tid < M2 ? 2 * tid : 0)); // w_F^(k1 * 2 tid)
+    if (tid < WSTEPS) {
+        // ... times 1/2: k_fwd_cols_r stores 2 C (its untangling without the halving)
+        const float2 t = tw_F(P, k1 * (uint32_t)(2 * NTB * tid));
+        tw_step[tid] = make_float2(0.5f * t.x, 0.5f * t.y);
+    }
+    if (!TWO && tid >= NTB - R0) { const int t = tid - (NTB - R0); leg[t] = tw_F(P, k1 * (uint32_t)(Q0 * t)); }
+    const float2 twa = tw_F(P, k1 * (uint32_t)(2 * tid < NS ? 2 * tid : 0)); // w_F^(k1 * 2 tid)
     const float2 wk1 = tw_F(P, k1);
+    const float2 wh = TWO ? tw_F(P, k1 * (uint32_t)NS) : make_float2(1.f, 0.f); // w_F^(k1 n): from c[j] to c[j + n]
     // stage twiddle seeds (they depend on the thread only): stage 0 / inverse stage 0, and the wave-local stage 1
-    const int j0 = tid < Q0 ? tid : 0;
-    const float2 s0w1 = P.tw2[j0], s0w4 = P.tw2[4 * j0];
-    const float2 tw0base = tw_F(P, k1 * (uint32_t)j0); // four-step factor of the thread's outputs of inverse stage 0
-    const int lane = tid & 63, wave = tid >> 6;
+    const int j0 = lt < Q0 ? lt : 0;
+    const float2 s0w1 = P.tw2[TWS * j0], s0w4 = P.tw2[TWS * 4 * j0];
+    const float2 tw0base = TWO ? make_float2(1.f, 0.f) : tw_F(P, k1 * (uint32_t)j0); // four-step factor of the outputs of inverse stage 0
+    const int lane = tid & 63, wave = lt >> 6;
     const int ul = lane / LPU, jl = lane - ul * LPU;
     const int j1c = jl < R2 ? jl : 0;
-    const float2 s1w1 = P.tw2[K1.twmul * j1c], s1w4 = P.tw2[(R1 > 4 ? 4 : 1) * K1.twmul * j1c];
+    const float2 s1w1 = P.tw2[TWS * K1.twmul * j1c], s1w4 = P.tw2[TWS * (R1 > 4 ? 4 : 1) * K1.twmul * j1c];
     __syncthreads(); // tw_step, leg
     static_for<0, WSTEPS>([&](auto I) __attribute__((always_inline)) {
         constexpr int i = decltype(I)::value;
-        const int q = tid + i * NT;
+        const int q = tid + i * NTB;
         if (q < HALF) {
             const float2 wa0 = cmul(twa, tw_step[i]), wa1 = cmul(wa0, wk1);
-            lds_put(A4 + 2 * q, mulw(Cx2{ v2f{ lx[I].x, ly[I].x }, v2f{ lx[I].y, ly[I].y } }, wa0));
-            lds_put(A4 + 2 * q + 1, mulw(Cx2{ v2f{ lx[I].z, ly[I].z }, v2f{ lx[I].w, ly[I].w } }, wa1));
+            const Cx2 c0 = mulw(Cx2{ v2f{ lx[I].x, ly[I].x }, v2f{ lx[I].y, ly[I].y } }, wa0);
+            const Cx2 c1 = mulw(Cx2{ v2f{ lx[I].z, ly[I].z }, v2f{ lx[I].w, ly[I].w } }, wa1);
+            if constexpr (!TWO) {
+                lds_put(A4 + 2 * q, c0);
+                lds_put(A4 + 2 * q + 1, c1);
+            } else {
+                float4 *base = reinterpret_cast<float4 *>(asx_lds_r);
+                const float2 wb0 = cmul(wa0, wh), wb1 = cmul(wa1, wh);
+                const Cx2 d0 = mulw(Cx2{ v2f{ lx2[I].x, ly2[I].x }, v2f{ lx2[I].y, ly2[I].y } }, wb0);
+                const Cx2 d1 = mulw(Cx2{ v2f{ lx2[I].z, ly2[I].z }, v2f{ lx2[I].w, ly2[I].w } }, wb1);
+                const float4 w2 = *reinterpret_cast<const float4 *>(P.tw2 + 2 * q); // w_M2^(2q), w_M2^(2q+1)
+                lds_put(base + 2 * q, c0 + d0);
+                lds_put(base + 2 * q + 1, c1 + d1);
+                lds_put(base + NS + 2 * q, mulw(c0 - d0, make_float2(w2.x, w2.y)));
+                lds_put(base + NS + 2 * q + 1, mulw(c1 - d1, make_float2(w2.z, w2.w)));
+            }
         }
     });
     __syncthreads();
 
     // ---- forward stage 0: butterflies j < Q0, legs Q0 apart ------------------------------------------------
-    for (int j = tid; j < Q0; j += NT) {
+    for (int j = lt; j < Q0; j += NT) {
         float4 *p = A4 + j;
         Cx2 v[R0];
         static_for<0, R0>([&](auto T) __attribute__((always_inline)) { v[T] = lds_get(p + decltype(T)::value * Q0); });
         float2 w1 = s0w1, w4 = s0w4;
-        if (j != tid) { w1 = P.tw2[j]; w4 = P.tw2[4 * j]; }
+        if (j != lt) { w1 = P.tw2[TWS * j]; w4 = P.tw2[TWS * 4 * j]; }
         float2 tww[R0];
         stage_twiddles_from<R0>(w1, w4, tww);
         Bfly<R0, false>::run(v);
@@ -199,24 +234,357 @@ __global__ __launch_bounds__(NT, ASX_ROWSR_WAVES) void k_rows_r(const AsxDev *__
     }
     __syncthreads();
 
-    // ---- inverse stage 0 from LDS, conjugate four-step twiddle, straight to HBM ----------------------------
+    // ---- inverse stage 0 from LDS -----------------------------------------------------------------------------
     float2 *go = qo + row;
-    for (int j = tid; j < Q0; j += NT) {
-        const float4 *p = A4 + j;
+    for (int j = lt; j < Q0; j += NT) {
+        float4 *p = A4 + j;
         Cx1 v[R0];
         static_for<0, R0>([&](auto T) __attribute__((always_inline)) { v[T] = lds_get1(p + decltype(T)::value * Q0); });
         float2 w1 = s0w1, w4 = s0w4, fb = tw0base;
-        if (j != tid) { w1 = P.tw2[j]; w4 = P.tw2[4 * j]; fb = tw_F(P, k1 * (uint32_t)j); }
+        if (j != lt) { w1 = P.tw2[TWS * j]; w4 = P.tw2[TWS * 4 * j]; if (!TWO) fb = tw_F(P, k1 * (uint32_t)j); }
         float2 tww[R0];
         stage_twiddles_from<R0>(w1, w4, tww);
         static_for<1, R0>([&](auto U) __attribute__((always_inline)) { v[U] = mulwc(v[U], tww[U]); });
         Bfly<R0, true>::run(v);
-        static_for<0, R0>([&](auto T) __attribute__((always_inline)) {
-            constexpr int t = decltype(T)::value;
-            const Cx1 y = mulwc(v[t], t == 0 ? fb : cmul(fb, leg[t]));
-            go[j + t * Q0] = make_float2(y.re, y.im);
+        if constexpr (!TWO) {
+            // conjugate four-step twiddle, straight to HBM
+            static_for<0, R0>([&](auto T) __attribute__((always_inline)) {
+                constexpr int t = decltype(T)::value;
+                const Cx1 y = mulwc(v[t], t == 0 ? fb : cmul(fb, leg[t]));
+                go[j + t * Q0] = make_float2(y.re, y.im);
+            });
+        } else {
+            static_for<0, R0>([&](auto T) __attribute__((always_inline)) { lds_put1(p + decltype(T)::value * Q0, v[T]); });
+        }
+    }
+    if constexpr (TWO) {
+        // the last radix-2 stage of the inverse, the conjugate four-step twiddle, 16 bytes per lane to HBM
+        __syncthreads();
+        const float4 *base = reinterpret_cast<const float4 *>(asx_lds_r);
+        static_for<0, WSTEPS>([&](auto I) __attribute__((always_inline)) {
+            constexpr int i = decltype(I)::value;
+            const int q = tid + i * NTB;
+            if (q < HALF) {
+                const Cx1 a0 = lds_get1(base + 2 * q), a1 = lds_get1(base + 2 * q + 1);
+                const Cx1 b0 = lds_get1(base + NS + 2 * q), b1 = lds_get1(base + NS + 2 * q + 1);
+                const float4 w2 = *reinterpret_cast<const float4 *>(P.tw2 + 2 * q);
+                const Cx1 t0 = mulwc(b0, make_float2(w2.x, w2.y)), t1 = mulwc(b1, make_float2(w2.z, w2.w));
+                // (tw_step carries the factor 1/2 of the load phase: taken out again with the factor 2)
+                const float2 ws = tw_step[i];
+                const float2 wa0 = cmul(twa, make_float2(2.f * ws.x, 2.f * ws.y)), wa1 = cmul(wa0, wk1);
+                const float2 wb0 = cmul(wa0, wh), wb1 = cmul(wa1, wh);
+                const Cx1 y0 = mulwc(a0 + t0, wa0), y1 = mulwc(a1 + t1, wa1);
+                const Cx1 z0 = mulwc(a0 - t0, wb0), z1 = mulwc(a1 - t1, wb1);
+                *reinterpret_cast<float4 *>(go + 2 * q) = make_float4(y0.re, y0.im, y1.re, y1.im);
+                *reinterpret_cast<float4 *>(go + NS + 2 * q) = make_float4(z0.re, z0.im, z1.re, z1.im);
+            }
         });
     }
+}
+
+// ---------------------------------------------------------------------------
+// Column tiles of the real-column kernels: T REAL columns j2 = c0 .. c0+T-1 of the [2 M1][M2] sample matrix, held
+// in LDS as [M1][T/2] float4 slots: slot (m, g) = { x[2m][c0+2g], x[2m+1][c0+2g], x[2m][c0+2g+1], x[2m+1][c0+2g+1] },
+// i.e. the complex sequences z[m] = x[2m] + i x[2m+1] of two adjacent columns side by side (the pair-planar form
+// of lds_fft.h).  A tile row is 4T bytes of the input (32 / T tiles share a 128-byte line: blocks b, b+8, ... of
+// one XCD, as in col_tile_of_block) and 8T bytes of C / Q.
+// ---------------------------------------------------------------------------
+__device__ __host__ __forceinline__ int rcol_line_log(int logT) { return logT >= 5 ? 0 : 5 - logT; } // log2(tiles per input line)
+__device__ __forceinline__ int rcol_tile_of_block(int b, int logT)
+{
+    const int ll = rcol_line_log(logT);
+    const int grp = 8 << ll;
+    return (b & ~(grp - 1)) + ((b & 7) << ll) + ((b >> 3) & ((1 << ll) - 1));
+}
+static inline unsigned rcol_grid_x(int ntiles, int logT)
+{
+    const unsigned grp = 8u << rcol_line_log(logT);
+    return ((unsigned)ntiles + grp - 1) / grp * grp;
+}
+
+#ifndef ASX_RABL
+#define ASX_RABL 0 // timing ablations (wrong results): 1 fwd: plain store, no untangle; 2 inv: plain fill, no tangle; 4 fwd: 64-byte input pieces
+#endif
+#ifndef ASX_RCOL_LOADS
+#define ASX_RCOL_LOADS 5 // row-pair pieces (two 16-byte loads each) a thread keeps in flight
+#endif
+
+// k_fwd_cols_r: grid (tiles, {source, sample}, npairs).  r2c column transforms of length 2 M1 (the zero half of the
+// sample -- rows j1 >= M1 -- is never loaded, src/cross_correlation.c:159-166): M1-point complex transform of the
+// packed rows, untangling between the slots of u and M1 - u, rows u and M1 - u of C (twice its value: the factor
+// is taken back by k_rows_r) stored in natural row order.
+template <class S1, int TC, int NT>
+__global__ __launch_bounds__(NT, 4) void k_fwd_cols_r(const AsxDev *__restrict__ Pp, const float *__restrict__ src,
+                                                       const float *__restrict__ smp, float2 *__restrict__ cx,
+                                                       float2 *__restrict__ cy, float *__restrict__ nrm_part, size_t pair_pitch)
+{
+    constexpr int M1 = S1::n, T = TC, logT = asx_ilog2(TC), H = T / 2, logH = logT - 1, Q4 = T / 4, logQ4 = logT - 2;
+    static_assert(T >= 4 && (M1 & 1) == 0, "four real columns per 16-byte load, an even number of packed rows");
+    const AsxDev &PD = *Pp;
+    const AsxKP P = asx_kp(PD);
+    __shared__ float nrm_red[NT / 64];
+    const bool is_smp = blockIdx.y != 0;
+    const size_t pair = blockIdx.z;
+    const int tile = rcol_tile_of_block(blockIdx.x, logT);
+    if (tile >= P.ntiles) return; // grid.x is rounded up
+    const int M2 = P.M2, c0 = tile * T;
+    const float *in = is_smp ? smp + pair * (size_t)P.N : src + pair * (size_t)(2u * P.N);
+    const int data_m = is_smp ? M1 / 2 : M1; // packed rows that are not zero padding
+    float2 *out = (is_smp ? cy : cx) + pair * pair_pitch;
+    float4 *lds4 = reinterpret_cast<float4 *>(asx_lds_r);
+    const LdsLayout Lc = col_layout(T, logT, NT);
+    const TwPre pre = tw_prefetch_first<S1, false, true>(Lc, P.tw1);
+
+    // work item e = (m, h): rows 2m and 2m+1, real columns c0 + 4h .. 4h+3 -> slots (m, 2h) and (m, 2h+1)
+    constexpr int NITEMS = M1 * Q4;
+    float ss = 0.f;
+    for (int e0 = threadIdx.x; e0 < NITEMS; e0 += ASX_RCOL_LOADS * NT) {
+        float4 a[ASX_RCOL_LOADS], b[ASX_RCOL_LOADS];
+        static_for<0, ASX_RCOL_LOADS>([&](auto I) __attribute__((always_inline)) {
+            const int e = e0 + decltype(I)::value * NT;
+            const int h = e & (Q4 - 1), m = e >> logQ4;
+            a[I] = b[I] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m < data_m) { // also false past the end of the tile (m >= M1 >= data_m)
+                const float *p = in + (size_t)(2 * m) * M2 + c0 + 4 * h;
+                if constexpr ((ASX_RABL & 4) != 0) { // the packed-sample kernels' pattern: one 8T-byte piece per row m
+                    const float *pp = in + 2 * ((size_t)m * M2 + c0) + 8 * h;
+                    a[I] = *reinterpret_cast<const float4 *>(pp);
+                    b[I] = *reinterpret_cast<const float4 *>(pp + 4);
+                } else {
+                a[I] = *reinterpret_cast<const float4 *>(p);
+                b[I] = *reinterpret_cast<const float4 *>(p + M2);
+                }
+            }
+        });
+        static_for<0, ASX_RCOL_LOADS>([&](auto I) __attribute__((always_inline)) {
+            const int e = e0 + decltype(I)::value * NT;
+            if (e < NITEMS) {
+                const int h = e & (Q4 - 1), m = e >> logQ4;
+                float4 *o = lds4 + (m << logH) + 2 * h;
+                o[0] = make_float4(a[I].x, b[I].x, a[I].y, b[I].y);
+                o[1] = make_float4(a[I].z, b[I].z, a[I].w, b[I].w);
+                ss = fmaf(a[I].x, a[I].x, fmaf(a[I].y, a[I].y, fmaf(a[I].z, a[I].z, fmaf(a[I].w, a[I].w, ss))));
+                ss = fmaf(b[I].x, b[I].x, fmaf(b[I].y, b[I].y, fmaf(b[I].z, b[I].z, fmaf(b[I].w, b[I].w, ss))));
+            }
+        });
+    }
+    // |source|^2 and |sample|^2 (the scale of the float32 error bound of the peak search) from the pass that reads
+    // the inputs anyway
+    ss = wave_sum_f32(ss);
+    if ((threadIdx.x & 63) == 0) nrm_red[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    lds_fft_static<S1, false, true>(lds4, Lc, P.tw1, pre);
+    if (threadIdx.x == 0) {
+        float t = nrm_red[0];
+        for (int w = 1; w < NT / 64; w++) t += nrm_red[w];
+        nrm_part[(pair * 2 + blockIdx.y) * (size_t)P.ntiles + tile] = t;
+    }
+    // untangle: Z[u] at slot sa, Z[M1-u] at slot sb ->  2 C[u] = S + w (-i D),  2 C[M1-u] = conj(S - w (-i D))
+    // with S = Z[u] + conj Z[M1-u], D = Z[u] - conj Z[M1-u], w = w_{2 M1}^u.  u = 0 pairs with itself and yields rows 0
+    // and M1; u = M1/2 pairs with itself and yields its row twice (the same value).
+    constexpr int NPAIRS = (M1 / 2 + 1) * H;
+    if constexpr ((ASX_RABL & 1) != 0) {
+        for (int e = threadIdx.x; e < (M1 << logH); e += NT) {
+            const int g = e & (H - 1), m = e >> logH;
+            *reinterpret_cast<float4 *>(out + (size_t)m * M2 + c0 + 2 * g) = lds4[e];
+        }
+        return;
+    }
+    for (int e = threadIdx.x; e < NPAIRS; e += NT) {
+        const int g = e & (H - 1), v = e >> logH;
+        const int4 cp = PD.col_pairs[v];
+        const float2 w = PD.col_tw[v];
+        const Cx2 za = lds_get(lds4 + (cp.y << logH) + g), zb = lds_get(lds4 + (cp.z << logH) + g);
+        const Cx2 S = Cx2{ za.re + zb.re, za.im - zb.im };
+        const Cx2 Dm = Cx2{ za.im + zb.im, zb.re - za.re }; // -i D
+        const Cx2 wd = mulw(Dm, w);
+        const Cx2 ca = S + wd, cb = S - wd;
+        const int u = cp.x;
+        float2 *oa = out + (size_t)u * M2 + c0 + 2 * g;
+        float2 *ob = out + (size_t)(M1 - u) * M2 + c0 + 2 * g;
+        *reinterpret_cast<float4 *>(oa) = make_float4(ca.re.x, ca.im.x, ca.re.y, ca.im.y);
+        *reinterpret_cast<float4 *>(ob) = make_float4(cb.re.x, -cb.im.x, cb.re.y, -cb.im.y);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_inv_cols_r: grid (tiles, npairs).  c2r column transforms of length 2 M1 from the rows k1 = 0 .. M1 of Q: tangling
+// between rows u and M1 - u into the slots of the M1-point inverse transform, whose outputs are the packed rows
+// z[m] = r[2m] + i r[2m+1] of the tile's T real columns; the last stage is consumed from registers (r reaches
+// neither HBM nor LDS): |.|-argmax with the reference's tie / sign / NaN rules (src/cross_correlation.c:52-67),
+// lags inside the float32 error window appended to the pair's candidate list, as in k_inv_cols.
+// Lag of component h of slot (m, g): h = 0 re0, 1 im0, 2 re1, 3 im1 -> (2m + (h & 1)) * M2 + c0 + 2g + (h >> 1).
+// ---------------------------------------------------------------------------
+template <class S1, int TC, int NT>
+__global__ __launch_bounds__(NT, 4) void k_inv_cols_r(const AsxDev *__restrict__ Pp, const float2 *__restrict__ qi, size_t pair_pitch,
+                                                       AsxPeakWs W, float *__restrict__ r_out)
+{
+    constexpr int M1 = S1::n, T = TC, logT = asx_ilog2(TC), H = T / 2, logH = logT - 1;
+    const AsxDev &PD = *Pp;
+    const AsxKP P = asx_kp(PD);
+    __shared__ asx_peak_t red[NT / 64];
+    __shared__ asx_peak_t s_run0;
+    __shared__ float s_b2;
+    const size_t pair = blockIdx.y;
+    const int tile = rcol_tile_of_block(blockIdx.x, logT);
+    if (tile >= P.ntiles) return;
+    // a digitally silent track: r is exactly zero everywhere, the running maximum stays zero = index 0 (see k_inv_cols)
+    if (W.bound2[pair] == 0.f && r_out == nullptr) return;
+    const double shift = W.shift ? W.shift[pair] : 0.0; // non-zero only in the second look (asx_api.hip)
+    const int M2 = P.M2, c0 = tile * T;
+    const float2 *in = qi + pair * pair_pitch;
+    float4 *lds4 = reinterpret_cast<float4 *>(asx_lds_r);
+    const LdsLayout Lc = col_layout(T, logT, NT);
+    if (threadIdx.x == 0) {
+        s_run0 = W.pairmax[pair];
+        s_b2 = W.bound2[pair];
+    }
+    const TwPre pre = tw_prefetch_first<S1, true, true, true>(Lc, P.tw1);
+    // tangle: Z'[u] = S + i conj(w) D,  Z'[M1-u] = conj(S) + i w conj(D),  S = Q[u] + conj Q[M1-u], D = Q[u] - conj Q[M1-u]
+    constexpr int NPAIRS = (M1 / 2 + 1) * H, STEPS = (NPAIRS + NT - 1) / NT;
+    if constexpr ((ASX_RABL & 2) != 0) {
+        constexpr int NE = M1 << logH, ST = (NE + NT - 1) / NT;
+        float4 v[ST];
+        static_for<0, ST>([&](auto I) __attribute__((always_inline)) {
+            const int e = threadIdx.x + decltype(I)::value * NT;
+            if (e < NE) v[I] = *reinterpret_cast<const float4 *>(in + (size_t)(e >> logH) * M2 + c0 + 2 * (e & (H - 1)));
+        });
+        static_for<0, ST>([&](auto I) __attribute__((always_inline)) {
+            const int e = threadIdx.x + decltype(I)::value * NT;
+            if (e < NE) lds4[e] = v[I];
+        });
+    } else {
+        float4 qa[STEPS], qb[STEPS];
+        int4 cps[STEPS];
+        static_for<0, STEPS>([&](auto I) __attribute__((always_inline)) {
+            const int e = threadIdx.x + decltype(I)::value * NT;
+            const int g = e & (H - 1), v = e >> logH;
+            cps[I] = PD.col_pairs[e < NPAIRS ? v : 0];
+            if (e < NPAIRS) {
+                qa[I] = *reinterpret_cast<const float4 *>(in + (size_t)cps[I].x * M2 + c0 + 2 * g);
+                qb[I] = *reinterpret_cast<const float4 *>(in + (size_t)(M1 - cps[I].x) * M2 + c0 + 2 * g);
+            }
+        });
+        static_for<0, STEPS>([&](auto I) __attribute__((always_inline)) {
+            const int e = threadIdx.x + decltype(I)::value * NT;
+            if (e < NPAIRS) {
+                const int g = e & (H - 1), v = e >> logH;
+                const float2 w = PD.col_tw[v];
+                const Cx2 a = Cx2{ v2f{ qa[I].x, qa[I].z }, v2f{ qa[I].y, qa[I].w } };
+                const Cx2 b = Cx2{ v2f{ qb[I].x, qb[I].z }, v2f{ qb[I].y, qb[I].w } };
+                const Cx2 S = Cx2{ a.re + b.re, a.im - b.im };
+                const Cx2 D = Cx2{ a.re - b.re, a.im + b.im };
+                const Cx2 t = mul_pos_i(mulwc(D, w));          // i conj(w) D
+                const Cx2 za = S + t;
+                // i w conj(D) = conj(-i conj(w) D) = -conj(t):  Z'[M1-u] = conj(S) - conj(t) = conj(S - t)
+                const Cx2 zb = S - t;
+                lds_put(lds4 + (cps[I].y << logH) + g, za);
+                if (cps[I].z != cps[I].y) lds_put(lds4 + (cps[I].z << logH) + g, Cx2{ zb.re, -zb.im });
+            }
+        });
+    }
+    __syncthreads();
+    const TwPre pre_last = lds_fft_static_head<S1, true, true>(lds4, Lc, P.tw1, pre);
+    const asx_peak_t run0 = s_run0;
+    const float b2 = s_b2;
+    auto last_stage = [&](auto &&sink) __attribute__((always_inline)) {
+        lds_last_stage_static<S1, true, true>(lds4, Lc, P.tw1, pre_last, sink);
+    };
+    const uint32_t uM2 = (uint32_t)M2;
+    // lag order inside a slot: re0 (i0), re1 (i0 + 1), im0 (i0 + M2), im1 (i0 + M2 + 1)
+    auto lag_of_max = [&](float4 s4, float m, uint32_t i0) {
+        return fabsf(s4.x) == m ? i0 : fabsf(s4.z) == m ? i0 + 1u : fabsf(s4.y) == m ? i0 + uM2 : i0 + uM2 + 1u;
+    };
+    const bool fast = (tile != 0) && (r_out == nullptr) && shift == 0.0;
+    auto examine_again = [&](float thr) __attribute__((always_inline)) {
+        last_stage([&](auto RC, auto &v, int g, int pos0, int q) __attribute__((always_inline)) {
+            static_for<0, decltype(RC)::value>([&](auto TT) __attribute__((always_inline)) {
+                constexpr int t = decltype(TT)::value;
+                const float val[4] = { v[t].re.x, v[t].im.x, v[t].re.y, v[t].im.y };
+                const uint32_t i0 = (uint32_t)(2 * (pos0 + t * q)) * uM2 + (uint32_t)(c0 + 2 * g);
+#pragma unroll
+                for (int h = 0; h < 4; h++) {
+                    const uint32_t idx = i0 + (uint32_t)(h & 1) * uM2 + (uint32_t)(h >> 1);
+                    const float key = shift == 0.0 ? peak_key_of(val[h], idx) : peak_key_shifted(val[h], idx, shift);
+                    if (key >= thr) cand_append(W, pair, idx, key);
+                }
+            });
+        });
+    };
+    float thr_again = 0.f;
+    bool again = false;
+    if (fast) {
+        float best_m = -INFINITY, second_m = -INFINITY;
+        uint32_t best_i0 = 0xFFFFFFFFu;
+        float4 gb = make_float4(0.f, 0.f, 0.f, 0.f);
+        last_stage([&](auto RC, auto &v, int g, int pos0, int q) __attribute__((always_inline)) {
+            static_for<0, decltype(RC)::value>([&](auto TT) __attribute__((always_inline)) {
+                constexpr int t = decltype(TT)::value;
+                const float4 s4 = make_float4(v[t].re.x, v[t].im.x, v[t].re.y, v[t].im.y);
+                const float m = fmaxf(fmaxf(fabsf(s4.x), fabsf(s4.y)), fmaxf(fabsf(s4.z), fabsf(s4.w))); // NaNs drop out
+                const uint32_t i0 = (uint32_t)(2 * (pos0 + t * q)) * uM2 + (uint32_t)(c0 + 2 * g);
+                if (m > best_m) { second_m = best_m; best_m = m; gb = s4; best_i0 = i0; }
+                else if (m == best_m) {
+                    // equal slot maxima (rare): the smaller lag stays; both count as near the maximum
+                    if (lag_of_max(s4, m, i0) < lag_of_max(gb, m, best_i0)) { gb = s4; best_i0 = i0; }
+                    second_m = m;
+                } else if (m > second_m) second_m = m;
+            });
+        });
+        const uint32_t my_idx = lag_of_max(gb, best_m, best_i0);
+        const float wmax = wave_max_nonneg(fmaxf(best_m, 0.f));
+        unsigned long long holders = __ballot(best_m == wmax);
+        uint32_t widx = 0xFFFFFFFFu;
+        while (holders) {
+            const int l = __ffsll((long long)holders) - 1;
+            const uint32_t li = (uint32_t)__builtin_amdgcn_readlane((int)my_idx, l);
+            widx = li < widx ? li : widx;
+            holders &= holders - 1;
+        }
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = widx == 0xFFFFFFFFu ? 0 : peak_pack_key(wmax, widx);
+        __syncthreads();
+        asx_peak_t tb = red[0];
+        for (int w = 1; w < NT / 64; w++) tb = peak_max(tb, red[w]);
+        if (threadIdx.x == 0) atomicMax(&W.pairmax[pair], tb);
+        const float thr = near_max_threshold(peak_key(peak_max(tb, run0)), b2);
+        thr_again = thr;
+        if (best_m >= thr) {
+            if (second_m >= thr) {
+                again = true;
+            } else {
+                const float val[4] = { gb.x, gb.y, gb.z, gb.w };
+#pragma unroll
+                for (int h = 0; h < 4; h++)
+                    if (fabsf(val[h]) >= thr) cand_append(W, pair, best_i0 + (uint32_t)(h & 1) * uM2 + (uint32_t)(h >> 1), fabsf(val[h]));
+            }
+        }
+    } else {
+        // general form: first tile (lag 0 competes signed), r dumped for tests, shifted keys of the second look
+        float best_key = -INFINITY;
+        uint32_t best_idx = 0xFFFFFFFFu;
+        last_stage([&](auto RC, auto &v, int g, int pos0, int q) __attribute__((always_inline)) {
+            static_for<0, decltype(RC)::value>([&](auto TT) __attribute__((always_inline)) {
+                constexpr int t = decltype(TT)::value;
+                const float val[4] = { v[t].re.x, v[t].im.x, v[t].re.y, v[t].im.y };
+                const uint32_t i0 = (uint32_t)(2 * (pos0 + t * q)) * uM2 + (uint32_t)(c0 + 2 * g);
+#pragma unroll
+                for (int h = 0; h < 4; h++) {
+                    const uint32_t idx = i0 + (uint32_t)(h & 1) * uM2 + (uint32_t)(h >> 1);
+                    const float key = shift == 0.0 ? peak_key_of(val[h], idx) : peak_key_shifted(val[h], idx, shift);
+                    if (key > best_key || (key == best_key && idx < best_idx) || best_idx == 0xFFFFFFFFu) { best_key = key; best_idx = idx; }
+                    if (r_out) r_out[pair * (size_t)P.nout + idx] = val[h];
+                }
+            });
+        });
+        asx_peak_t best = best_idx == 0xFFFFFFFFu ? 0 : peak_pack_key(best_key, best_idx);
+        best = block_peak_max(best, red);
+        if (threadIdx.x == 0) { atomicMax(&W.pairmax[pair], best); red[0] = best; }
+        __syncthreads();
+        const float thr = near_max_threshold(peak_key(peak_max(red[0], run0)), b2);
+        again = best_key >= thr;
+        thr_again = thr;
+    }
+    if (again) examine_again(thr_again);
 }
 
 // ---------------------------------------------------------------------------
@@ -237,14 +605,71 @@ bool asx_launch_rows_r(const AsxDev &P, const float2 *cx, const float2 *cy, floa
     const int nrows = P.M1 + 1;
     const size_t pitch = (size_t)nrows * (size_t)P.M2;
     const size_t lds = (size_t)P.M2 * sizeof(float4);
-#define ASX_ROWSR_CASE(nt, n, ...)                                                                                              \
-    if (schedule_is_r(P.st2, n, { __VA_ARGS__ })) {                                                                             \
-        hipLaunchKernelGGL((k_rows_r<Sched<n, __VA_ARGS__>, nt>), dim3((unsigned)nrows * (unsigned)npairs), dim3(nt), lds, s,   \
-                           P.self_dev, cx, cy, q, nrows, pitch, W);                                                             \
+    // chosen by the row length alone: these kernels carry their own schedule and only read the plan's w_M2 table
+#define ASX_ROWSR_CASE(nt, two, n, ...)                                                                                         \
+    if (P.M2 == ((two) ? 2 * n : n)) {                                                                                          \
+        hipLaunchKernelGGL((k_rows_r<Sched<n, __VA_ARGS__>, nt, two>), dim3((unsigned)nrows * (unsigned)npairs),                \
+                           dim3((two) ? 2 * nt : nt), lds, s, P.self_dev, cx, cy, q, nrows, pitch, W);                          \
         return true;                                                                                                            \
     }
-    ASX_ROWSR_CASE(128, 1200, 12, 10, 10)
-    ASX_ROWSR_CASE(128, 480, 10, 8, 6)
+    ASX_ROWSR_CASE(128, false, 1200, 12, 10, 10)
+    ASX_ROWSR_CASE(128, true, 1200, 12, 10, 10)
+    ASX_ROWSR_CASE(128, false, 480, 10, 8, 6)
 #undef ASX_ROWSR_CASE
     return false;
+}
+
+// Column schedules of the production sample lengths (plan_math.cpp's tuned table):  X(M1, tile width in real columns,
+// block size, radices...)
+#define ASX_RCOLS(X) \
+    X(1200, 8, 512, 12, 10, 10) X(800, 8, 320, 10, 10, 8) X(600, 16, 512, 10, 10, 6) X(400, 16, 320, 10, 8, 5) X(300, 16, 256, 10, 6, 5)
+
+static void allow_big_lds_r(const void *fn, size_t bytes)
+{
+    if (bytes > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+bool asx_launch_fwd_cols_r(const AsxDev &P, const float *src, const float *smp, float2 *cx, float2 *cy, const AsxPeakWs &W,
+                           int npairs, hipStream_t s)
+{
+    if (!P.col_pairs) return false;
+    const size_t pitch = ((size_t)P.M1 + 1) * (size_t)P.M2, lds = (size_t)P.M1 * P.T * sizeof(float2);
+    const dim3 grid(rcol_grid_x(P.ntiles, P.logT), 2, npairs);
+#define ASX_TRY(m1, t, nt, ...)                                                                                             \
+    if (P.T == (t) && schedule_is_r(P.st1, m1, { __VA_ARGS__ })) {                                                          \
+        allow_big_lds_r((const void *)k_fwd_cols_r<Sched<m1, __VA_ARGS__>, t, nt>, lds);                                    \
+        hipLaunchKernelGGL((k_fwd_cols_r<Sched<m1, __VA_ARGS__>, t, nt>), grid, dim3(nt), lds, s, P.self_dev, src, smp, cx, cy, \
+                           W.nrm_part, pitch);                                                                              \
+        return true;                                                                                                        \
+    }
+    ASX_RCOLS(ASX_TRY)
+#undef ASX_TRY
+    return false;
+}
+
+bool asx_launch_inv_cols_r(const AsxDev &P, const float2 *q, const AsxPeakWs &W, float *r_out, int npairs, hipStream_t s)
+{
+    if (!P.col_pairs) return false;
+    const size_t pitch = ((size_t)P.M1 + 1) * (size_t)P.M2, lds = (size_t)P.M1 * P.T * sizeof(float2);
+    const dim3 grid(rcol_grid_x(P.ntiles, P.logT), npairs);
+#define ASX_TRY(m1, t, nt, ...)                                                                                             \
+    if (P.T == (t) && schedule_is_r(P.st1, m1, { __VA_ARGS__ })) {                                                          \
+        allow_big_lds_r((const void *)k_inv_cols_r<Sched<m1, __VA_ARGS__>, t, nt>, lds);                                    \
+        hipLaunchKernelGGL((k_inv_cols_r<Sched<m1, __VA_ARGS__>, t, nt>), grid, dim3(nt), lds, s, P.self_dev, q, pitch, W, r_out); \
+        return true;                                                                                                        \
+    }
+    ASX_RCOLS(ASX_TRY)
+#undef ASX_TRY
+    return false;
+}
+
+bool asx_rlayout_available(const AsxDev &P)
+{
+    if (!P.col_pairs || P.nout != P.F) return false;
+    bool cols = false, rows = false;
+#define ASX_TRY(m1, t, nt, ...) if (P.T == (t) && schedule_is_r(P.st1, m1, { __VA_ARGS__ })) cols = true;
+    ASX_RCOLS(ASX_TRY)
+#undef ASX_TRY
+    rows = P.M2 == 1200 || P.M2 == 480 || P.M2 == 2400;
+    return cols && rows;
 }

@@ -76,38 +76,6 @@ extern __shared__ __attribute__((aligned(16))) float2 asx_lds[];
 // {re0, im0, re1, im1} (lds_fft.h), so one thread transforms two columns with shared
 // twiddles and b128 LDS accesses, and tiles move in and out without a shuffle.
 // ---------------------------------------------------------------------------
-// Tile <-> block mapping of the column kernels.  A tile row is T complex values = 8T bytes; L = 16/T tiles
-// share a 128-byte L2 line (T = 8: two tiles, 64 bytes each).  Blocks are dealt round-robin over the 8
-// XCDs (each with a private L2), so with the identity mapping the pieces of a line are fetched by different
-// L2s: the PMC read counters showed exactly 2x the needed bytes at T = 8.  This mapping puts the L tiles of
-// a line on blocks b, b + 8, ..., b + 8(L-1) (same XCD, dispatched together), so all but the first hit in
-// L2.  Speed only; any placement is correct.  Grids are rounded up to a multiple of 8L blocks.
-__device__ __host__ __forceinline__ int col_tiles_per_line_log(int logT) { return logT >= 4 ? 0 : 4 - logT; }
-__device__ __forceinline__ int col_tile_of_block(int b, int logT)
-{
-    const int ll = col_tiles_per_line_log(logT);       // log2 L
-    const int grp = 8 << ll;                           // blocks that cover 8 lines
-    return (b & ~(grp - 1)) + ((b & 7) << ll) + ((b >> 3) & ((1 << ll) - 1));
-}
-static inline unsigned col_grid_x(int ntiles, int logT)
-{
-    const unsigned grp = 8u << col_tiles_per_line_log(logT);
-    return ((unsigned)ntiles + grp - 1) / grp * grp;
-}
-
-__device__ __forceinline__ LdsLayout col_layout(int T, int logT, int nthreads)
-{
-    LdsLayout L;
-    L.ngroups = T >> 1;
-    L.log_ngroups = logT - 1;
-    L.elem_stride = T >> 1;
-    L.group_stride = 1;
-    L.nthreads = nthreads;
-    L.tid = threadIdx.x;
-    return L;
-}
-constexpr int asx_ilog2(int v) { return v <= 1 ? 0 : 1 + asx_ilog2(v >> 1); }
-
 // k_fwd_cols: grid (ntiles, 2, npairs).  blockIdx.y: 0 = source, 1 = sample.
 // Packs real samples as complex (z[j] = x[2j] + i x[2j+1]); zero padding and the periodic
 // extension of the source (embedded lengths) happen in the loads, never in HBM.
@@ -567,110 +535,9 @@ __device__ __forceinline__ double wave_sum(double v)
 }
 
 // ---------------------------------------------------------------------------
-// peak search helpers (src/cross_correlation.c:52-67)
-// ---------------------------------------------------------------------------
-// key(0) = arr[0] SIGNED (:56), key(i) = fabs(arr[i]) (:59).  A NaN key never wins the strict
-// '>' of :60 (so it needs no mapping in a running maximum); a NaN at index 0 is never beaten.
-__device__ __forceinline__ float peak_key_of(float value, uint32_t idx)
-{
-    const float a = fabsf(value);
-    const float z = (value != value) ? INFINITY : (value + 0.0f); // -0.0 -> +0.0 so it ties with |0|
-    return idx == 0u ? z : a;
-}
-// The same when the transforms ran on (source - mean) (second look at a pair with a large offset in both tracks,
-// second_look, asx_api.hip): r[k] = value + c with c = mean * sum(sample), the same for every k.  Keys are taken RELATIVE to
-// |c| -- key' = |r| - |c|, lag 0: r - |c| -- so that float32 keeps the differences between lags when |c| >> |value|;
-// a common shift changes neither the order of the keys nor the width of the near-maximum window.
-__device__ __forceinline__ float peak_key_shifted(float value, uint32_t idx, double c)
-{
-    if (value != value) return idx == 0u ? INFINITY : value;
-    const double r = (double)value + c;
-    return (float)((idx == 0u ? r : fabs(r)) - fabs(c)) + 0.0f;
-}
-__device__ __forceinline__ asx_peak_t peak_pack_key(float key, uint32_t idx)
-{
-    if (key != key) key = -INFINITY;
-    uint32_t b = __float_as_uint(key);
-    b = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
-    return ((asx_peak_t)b << 32) | (asx_peak_t)(0xFFFFFFFFu - idx);
-}
-
-__device__ __forceinline__ asx_peak_t peak_max(asx_peak_t a, asx_peak_t b) { return a > b ? a : b; }
-
-__device__ __forceinline__ asx_peak_t wave_peak_max(asx_peak_t v)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const asx_peak_t o = __shfl_xor(v, off, 64);
-        v = peak_max(v, o);
-    }
-    return v;
-}
-
-// block-wide max; result valid in thread 0.  `scratch` = one entry per wave of the block.
-__device__ __forceinline__ asx_peak_t block_peak_max(asx_peak_t v, asx_peak_t *scratch)
-{
-    v = wave_peak_max(v);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) scratch[wave] = v;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const int nwaves = (blockDim.x + 63) >> 6;
-        for (int w = 1; w < nwaves; w++) v = peak_max(v, scratch[w]);
-    }
-    return v;
-}
-
-// Wave-wide maximum of non-negative floats without LDS traffic: four DPP steps leave every lane of
-// a 16-lane row with the row's maximum, three readlanes combine the rows.  (__shfl_xor goes through
-// ds_bpermute: one LDS round trip per step.)
-__device__ __forceinline__ float wave_max_nonneg(float v)
-{
-#define ASX_DPP_MAX(ctrl) v = fmaxf(v, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), (ctrl), 0xF, 0xF, true)))
-    ASX_DPP_MAX(0xB1);  // quad_perm [1,0,3,2]
-    ASX_DPP_MAX(0x4E);  // quad_perm [2,3,0,1]
-    ASX_DPP_MAX(0x141); // row_half_mirror
-    ASX_DPP_MAX(0x140); // row_mirror
-#undef ASX_DPP_MAX
-    const int b = __float_as_int(v);
-    const float r0 = __int_as_float(__builtin_amdgcn_readlane(b, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(b, 16));
-    const float r2 = __int_as_float(__builtin_amdgcn_readlane(b, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(b, 48));
-    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
-}
-
-// ---------------------------------------------------------------------------
 // k_inv_cols: grid (ntiles, npairs).  Inverse column transforms; the time-domain
 // correlation r[2j] = Re g[j], r[2j+1] = Im g[j] only lives in LDS/registers.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ float peak_key(asx_peak_t v)
-{
-    uint32_t b = (uint32_t)(v >> 32);
-    b = (b & 0x80000000u) ? (b & 0x7FFFFFFFu) : ~b;
-    return __uint_as_float(b);
-}
-__device__ __forceinline__ uint32_t peak_index(asx_peak_t v) { return 0xFFFFFFFFu - (uint32_t)(v & 0xFFFFFFFFull); }
-// Everything at or above this key is "as large as the maximum" for float32 transforms: b2 = 2B,
-// B = the bound on |float32 r[k] - exact r[k]| (asx_internal.h).  If the exact maximum is at k*, then
-// key32(k*) >= exact(k*) - B >= exact(kmax32) - B >= key32(kmax32) - 2B.
-__device__ __forceinline__ float near_max_threshold(float kmax, float b2) { return kmax - b2; }
-
-// Append one near-maximum lag to the pair's candidate list (called from divergent code: the lanes of
-// the wave that are here together take ONE slot range with one atomic).
-__device__ __forceinline__ void cand_append(const AsxPeakWs &W, size_t pair, uint32_t idx, float key)
-{
-    const unsigned long long m = __ballot(1);
-    const int lane = threadIdx.x & 63;
-    const int leader = __ffsll((long long)m) - 1;
-    uint32_t base = 0;
-    if (lane == leader) base = atomicAdd(&W.cand_n[pair], (uint32_t)__popcll(m));
-    base = (uint32_t)__shfl((int)base, leader, 64);
-    const uint32_t slot = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-    if (slot < W.cap) {
-        AsxCand c; c.idx = idx; c.key = key;
-        W.cand[pair * (size_t)W.cap + slot] = c;
-    }
-}
-
 template <int MAXR, class S1 = void, int TC = 0, int NT = 0>
 __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_inv_cols(const AsxDev *__restrict__ Pp, const float2 *__restrict__ ga,
                                                                    AsxPeakWs W, float *__restrict__ r_out)
@@ -1613,6 +1480,7 @@ static bool generic_only()
 void asx_launch_fwd_cols(const AsxDev &P, const float *src, const float *smp, float2 *zxa,
                          float2 *zya, const AsxPeakWs &W, int npairs, hipStream_t s)
 {
+    if (P.rlayout && asx_launch_fwd_cols_r(P, src, smp, zxa, zya, W, npairs, s)) return;
     if (generic_only() || !asx_launch_fwd_cols_static(P, src, smp, zxa, zya, W, npairs, s))
         asx_launch_fwd_cols_generic(P, src, smp, zxa, zya, W, npairs, s);
 }
@@ -1620,9 +1488,8 @@ void asx_launch_fwd_cols(const AsxDev &P, const float *src, const float *smp, fl
 void asx_launch_rows(const AsxDev &P, const float2 *zxa, const float2 *zya, float2 *ga,
                      const AsxPeakWs &W, int npairs, hipStream_t s)
 {
+    if (P.rlayout && asx_launch_rows_r(P, zxa, zya, ga, W, npairs, s)) return;
     if (!generic_only() && asx_launch_rows2(P, zxa, zya, ga, W, npairs, s)) return; // two LDS passes per transform
-    static const bool time_r = getenv("ASX_TIME_ROWS_R") != nullptr; // timing probe: right traffic, meaningless results
-    if (time_r && asx_launch_rows_r(P, zxa, zya, ga, W, npairs, s)) return;
     if (generic_only() || !asx_launch_rows_static(P, zxa, zya, ga, W, npairs, s))
         asx_launch_rows_generic(P, zxa, zya, ga, W, npairs, s);
 }
@@ -1630,6 +1497,7 @@ void asx_launch_rows(const AsxDev &P, const float2 *zxa, const float2 *zya, floa
 void asx_launch_inv_cols(const AsxDev &P, const float2 *ga, const AsxPeakWs &W, float *r_out, int npairs,
                          hipStream_t s)
 {
+    if (P.rlayout && asx_launch_inv_cols_r(P, ga, W, r_out, npairs, s)) return;
     if (generic_only() || !asx_launch_inv_cols_static(P, ga, W, r_out, npairs, s))
         asx_launch_inv_cols_generic(P, ga, W, r_out, npairs, s);
 }

@@ -157,6 +157,69 @@ def device_xcorr(source, sample, M1=None, M2=None):
     return r[: 2 * N]
 
 
+# ---------------------------------------------------------------------------
+# The real-column decomposition (csrc/rlayout.hip): the real sequence is the matrix x[j1][j2],
+# j = j1*M2 + j2, with 2*M1 rows; k = k1 + 2*M1*k2.  Mirrors k_fwd_cols_r / k_rows_r / k_inv_cols_r
+# step by step (packed rows, untangling inside the tile, row k1 independent, tangling inside the tile).
+# ---------------------------------------------------------------------------
+
+def rlayout_fwd_cols(x, M1, M2):
+    """k_fwd_cols_r: x real, length 2*M1*M2 -> 2*C[k1][j2], k1 = 0..M1 (the factor 2 is taken back by the rows)"""
+    X = np.asarray(x, dtype=float).reshape(2 * M1, M2)
+    z = X[0::2] + 1j * X[1::2]                       # packed rows z[m] = x[2m] + i x[2m+1]
+    Z = np.fft.fft(z, axis=0)                        # M1-point complex transform down the columns
+    C2 = np.zeros((M1 + 1, M2), dtype=complex)
+    for u in range(M1 // 2 + 1):
+        za, zb = Z[u], Z[(M1 - u) % M1]
+        S = za + np.conj(zb)
+        Dm = -1j * (za - np.conj(zb))
+        w = tw(2 * M1, u)
+        C2[u] = S + w * Dm
+        C2[M1 - u] = np.conj(S - w * Dm)
+    return C2
+
+
+def rlayout_rows(C2x, C2y, M1, M2):
+    """k_rows_r: every row k1 on its own -- four-step twiddle (times 1/2), forward row transforms of both spectra,
+    X conj(Y), inverse row transform, conjugate four-step twiddle -> Q[k1][j2]"""
+    F = 2 * M1 * M2
+    k1 = np.arange(M1 + 1)[:, None]
+    j2 = np.arange(M2)[None, :]
+    f = tw(F, k1 * j2)
+    X = np.fft.fft(0.5 * C2x * f, axis=1)            # X[k1 + 2 M1 k2] at [k1][k2]
+    Y = np.fft.fft(0.5 * C2y * f, axis=1)
+    P = X * np.conj(Y)
+    return np.fft.ifft(P, axis=1) * M2 * np.conj(f)  # unnormalised inverse
+
+
+def rlayout_inv_cols(Q, M1, M2):
+    """k_inv_cols_r: tangling of rows u and M1-u into the slots of the M1-point inverse transform, whose outputs are
+    the packed rows z[m] = r[2m] + i r[2m+1]"""
+    Zp = np.zeros((M1, M2), dtype=complex)
+    for u in range(M1 // 2 + 1):
+        qa, qb = Q[u], Q[M1 - u]
+        S = qa + np.conj(qb)
+        D = qa - np.conj(qb)
+        t = 1j * np.conj(tw(2 * M1, u)) * D
+        Zp[u] = S + t
+        if (M1 - u) % M1 != u:
+            Zp[M1 - u] = np.conj(S - t)
+    z = np.fft.ifft(Zp, axis=0) * M1                 # unnormalised
+    r = np.zeros((2 * M1, M2))
+    r[0::2] = z.real
+    r[1::2] = z.imag
+    return r.reshape(-1)
+
+
+def rlayout_xcorr(source, sample, M1, M2):
+    """whole real-column pipeline -> r[0..2N), F = 2N = 2*M1*M2 (never embedded); r is F times the sum of products"""
+    N = len(sample)
+    assert 2 * N == 2 * M1 * M2 and M1 % 2 == 0
+    t = np.zeros(2 * N); t[:N] = sample
+    Q = rlayout_rows(rlayout_fwd_cols(source, M1, M2), rlayout_fwd_cols(t, M1, M2), M1, M2)
+    return rlayout_inv_cols(Q, M1, M2)
+
+
 def split(M):
     best = (1, M)
     for a in range(1, int(M ** 0.5) + 1):

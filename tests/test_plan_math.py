@@ -105,3 +105,16 @@ def test_measured_mode_candidates_are_valid_splits(n):
         assert (d["M1"], d["M2"], d["T"]) == (m1, m2, t)
         assert m1 * m2 * 2 == base["F"] and d["F"] == base["F"]
         assert t >= 2 and (t & (t - 1)) == 0 and m1 * t * 8 <= 80 * 1024 and 4 * m2 * 8 <= 64 * 1024
+
+
+@pytest.mark.parametrize("m1,m2", [(4, 8), (6, 4), (10, 12), (12, 20), (30, 16)])
+def test_real_column_decomposition_matches_the_reference_recipe(m1, m2):
+    """csrc/rlayout.hip's algebra (model_fourstep.rlayout_*): r2c columns with the untangling inside the tile, rows
+    k1 = 0..M1 independent, c2r columns -- equals rfft * conj(rfft) -> irfft of src/cross_correlation.c:204-239"""
+    n = m1 * m2
+    rng = np.random.default_rng(m1 * 100 + m2)
+    src = rng.standard_normal(2 * n)
+    smp = rng.standard_normal(n)
+    r = model.rlayout_xcorr(src, smp, m1, m2)
+    ref = model.reference_r(src, smp)
+    assert np.abs(r - ref).max() < 1e-9 * np.abs(ref).max()
