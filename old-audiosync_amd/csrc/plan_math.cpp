@@ -197,13 +197,21 @@ std::string asx_host_plan_build(size_t N, const char *split_override, AsxHostPla
     int M1 = 0, M2 = 0, T = 0;
     // Measured-best splits for the reference's six interval lengths (src/audiosync.c:50-57) on
     // MI355X, from tools/tune.py (batched float32 path).  Other lengths use the cost model below.
-    static const struct { uint32_t M; const char *split; } kTuned[] = {
-        { 144000u, "300x480x16" }, { 288000u, "600x480x16" }, { 480000u, "400x1200x16" },
-        { 720000u, "600x1200x16" }, { 960000u, "800x1200x8" }, { 1440000u, "1200x1200x8" },
+    // The two longest lengths take 2400-point rows so that their column tiles are 400 / 600 packed rows of SIXTEEN real
+    // columns (64-byte input pieces, whole 128-byte lines of the intermediates): with 800 / 1200 rows a tile holds eight,
+    // and the real-column kernels (rlayout.hip) then re-fetch input lines between four sibling tiles (round 4, measured:
+    // k_fwd_cols_r 6.15 GB against 5.09 GB per launch).  $ASX_LAYOUT=packed (the packed-sample kernels, xcorr_kernels.hip)
+    // keeps round 3's table: its row kernels have no 2400-point schedule compiled in.
+    static const struct { uint32_t M; const char *split; const char *split_packed; } kTuned[] = {
+        { 144000u, "300x480x16", nullptr }, { 288000u, "600x480x16", nullptr }, { 480000u, "400x1200x16", nullptr },
+        { 720000u, "600x1200x16", nullptr }, { 960000u, "400x2400x16", "800x1200x8" },
+        { 1440000u, "600x2400x16", "1200x1200x8" },
     };
     if (!(split_override && *split_override)) {
+        const char *lay = getenv("ASX_LAYOUT");
+        const bool packed = (lay && !strcmp(lay, "packed")) || getenv("ASX_GENERIC") || (getenv("ASX_ROWS2") && atoi(getenv("ASX_ROWS2")) != 0);
         for (const auto &t : kTuned)
-            if (t.M == M && F == 2 * (uint64_t)N) split_override = t.split;
+            if (t.M == M && F == 2 * (uint64_t)N) split_override = (packed && t.split_packed) ? t.split_packed : t.split;
     }
     if (split_override && *split_override) {
         if (sscanf(split_override, "%dx%dx%d", &M1, &M2, &T) != 3 || M1 < 1 || M2 < 1 ||

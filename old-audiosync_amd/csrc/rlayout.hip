@@ -373,37 +373,73 @@ __global__ __launch_bounds__(NT, 4) void k_fwd_cols_r(const AsxDev *__restrict__
     ss = wave_sum_f32(ss);
     if ((threadIdx.x & 63) == 0) nrm_red[threadIdx.x >> 6] = ss;
     __syncthreads();
-    lds_fft_static<S1, false, true>(lds4, Lc, P.tw1, pre);
+    (void)lds_fft_static_head<S1, false, true>(lds4, Lc, P.tw1, pre); // every stage but the innermost one
     if (threadIdx.x == 0) {
         float t = nrm_red[0];
         for (int w = 1; w < NT / 64; w++) t += nrm_red[w];
         nrm_part[(pair * 2 + blockIdx.y) * (size_t)P.ntiles + tile] = t;
     }
-    // untangle: Z[u] at slot sa, Z[M1-u] at slot sb ->  2 C[u] = S + w (-i D),  2 C[M1-u] = conj(S - w (-i D))
-    // with S = Z[u] + conj Z[M1-u], D = Z[u] - conj Z[M1-u], w = w_{2 M1}^u.  u = 0 pairs with itself and yields rows 0
-    // and M1; u = M1/2 pairs with itself and yields its row twice (the same value).
-    constexpr int NPAIRS = (M1 / 2 + 1) * H;
-    if constexpr ((ASX_RABL & 1) != 0) {
-        for (int e = threadIdx.x; e < (M1 << logH); e += NT) {
-            const int g = e & (H - 1), m = e >> logH;
-            *reinterpret_cast<float4 *>(out + (size_t)m * M2 + c0 + 2 * g) = lds4[e];
+    // ---- the innermost stage (radix RL, RL consecutive slots per butterfly, no twiddles), untangling and the stores, all
+    // from registers.  Butterfly b of a column pair yields the frequencies u_b + MB t (t < RL, MB = M1 / RL, u_b = digit
+    // swap of b); their untangling partners M1 - u_b - MB t are element RL-1-t of butterfly b' (u_b' = MB - u_b).  A work
+    // item runs BOTH butterflies and stores the 2 RL rows
+    //     2 C[u] = S + w (-i D),  2 C[M1-u] = conj(S - w (-i D)),  S = Z[u] + conj Z[M1-u], D = Z[u] - conj Z[M1-u], w = w_{2 M1}^u
+    // (w = w_{2 M1}^u_b times the compile-time root w_{2 RL}^t): no LDS pass for the result, no index table.  The two
+    // butterflies that pair with themselves (u_b = 0, whose partners are its own elements RL - t and which also yields
+    // row M1; u_b = MB/2) share the work item v = 0.
+    static_assert(S1::nstages == 3, "three-stage column schedules");
+    constexpr int RL = S1::stage(2).R, R0c = S1::stage(0).R, R1c = S1::stage(1).R, MB = M1 / RL;
+    static_assert(S1::stage(2).q == 1 && MB == R0c * R1c && MB % 2 == 0, "innermost stage of consecutive slots");
+    constexpr int NBPAIRS = (MB / 2) * H;
+    for (int e = threadIdx.x; e < NBPAIRS; e += NT) {
+        const int g = e & (H - 1), v = e >> logH;  // v = u_b in [0, MB/2)
+        const int ub = v, ubp = v == 0 ? MB / 2 : MB - v;
+        const int d1 = ub / R0c, d0 = ub - d1 * R0c, e1 = ubp / R0c, e0 = ubp - e1 * R0c;
+        const float4 *pa = lds4 + (((d0 * R1c + d1) * RL) << logH) + g, *pb = lds4 + (((e0 * R1c + e1) * RL) << logH) + g;
+        Cx2 za[RL], zb[RL];
+        static_for<0, RL>([&](auto TT) __attribute__((always_inline)) {
+            za[TT] = lds_get(pa + (decltype(TT)::value << logH));
+            zb[TT] = lds_get(pb + (decltype(TT)::value << logH));
+        });
+        Bfly<RL, false>::run(za);
+        Bfly<RL, false>::run(zb);
+        const int cg = 2 * g;
+        auto row = [&](int u, Cx2 c, bool conj) __attribute__((always_inline)) {
+            *reinterpret_cast<float4 *>(out + (size_t)u * M2 + c0 + cg) = conj ? make_float4(c.re.x, -c.im.x, c.re.y, -c.im.y)
+                                                                           : make_float4(c.re.x, c.im.x, c.re.y, c.im.y);
+        };
+        if (v != 0) {
+            const float2 wu = tw_F(P, (uint32_t)ub * (uint32_t)M2); // w_{2 M1}^u_b = w_F^(u_b M2)
+            static_for<0, RL>([&](auto TT) __attribute__((always_inline)) {
+                constexpr int t = decltype(TT)::value;
+                const Cx2 a = za[t], bq = zb[RL - 1 - t];
+                const Cx2 S = Cx2{ a.re + bq.re, a.im - bq.im };
+                const Cx2 Dm = Cx2{ a.im + bq.im, bq.re - a.re }; // -i D
+                const Cx2 wd = mul_root<2 * RL, t, false>(mulw(Dm, wu));
+                row(ub + MB * t, S + wd, false);
+                row(ubp + MB * (RL - 1 - t), S - wd, true);
+            });
+        } else {
+            // u_b = 0: Z[MB t] pairs with Z[MB (RL - t)] (t = 0 with itself: rows 0 and M1); w = w_{2 RL}^t
+            static_for<0, RL>([&](auto TT) __attribute__((always_inline)) {
+                constexpr int t = decltype(TT)::value;
+                const Cx2 a = za[t], bq = za[(RL - t) % RL];
+                const Cx2 S = Cx2{ a.re + bq.re, a.im - bq.im };
+                const Cx2 Dm = Cx2{ a.im + bq.im, bq.re - a.re };
+                const Cx2 wd = mul_root<2 * RL, t, false>(Dm);
+                row(MB * t, S + wd, false);
+                if constexpr (t == 0) row(M1, S - wd, true);
+            });
+            // u_b = MB/2: Z[MB/2 + MB t] pairs with Z[MB/2 + MB (RL-1-t)]; w = w_{4 RL}^(2t + 1)
+            static_for<0, RL>([&](auto TT) __attribute__((always_inline)) {
+                constexpr int t = decltype(TT)::value;
+                const Cx2 a = zb[t], bq = zb[RL - 1 - t];
+                const Cx2 S = Cx2{ a.re + bq.re, a.im - bq.im };
+                const Cx2 Dm = Cx2{ a.im + bq.im, bq.re - a.re };
+                const Cx2 wd = mul_root<4 * RL, 2 * t + 1, false>(Dm);
+                row(MB / 2 + MB * t, S + wd, false);
+            });
         }
-        return;
-    }
-    for (int e = threadIdx.x; e < NPAIRS; e += NT) {
-        const int g = e & (H - 1), v = e >> logH;
-        const int4 cp = PD.col_pairs[v];
-        const float2 w = PD.col_tw[v];
-        const Cx2 za = lds_get(lds4 + (cp.y << logH) + g), zb = lds_get(lds4 + (cp.z << logH) + g);
-        const Cx2 S = Cx2{ za.re + zb.re, za.im - zb.im };
-        const Cx2 Dm = Cx2{ za.im + zb.im, zb.re - za.re }; // -i D
-        const Cx2 wd = mulw(Dm, w);
-        const Cx2 ca = S + wd, cb = S - wd;
-        const int u = cp.x;
-        float2 *oa = out + (size_t)u * M2 + c0 + 2 * g;
-        float2 *ob = out + (size_t)(M1 - u) * M2 + c0 + 2 * g;
-        *reinterpret_cast<float4 *>(oa) = make_float4(ca.re.x, ca.im.x, ca.re.y, ca.im.y);
-        *reinterpret_cast<float4 *>(ob) = make_float4(cb.re.x, -cb.im.x, cb.re.y, -cb.im.y);
     }
 }
 
@@ -439,52 +475,77 @@ __global__ __launch_bounds__(NT, 4) void k_inv_cols_r(const AsxDev *__restrict__
         s_run0 = W.pairmax[pair];
         s_b2 = W.bound2[pair];
     }
-    const TwPre pre = tw_prefetch_first<S1, true, true, true>(Lc, P.tw1);
-    // tangle: Z'[u] = S + i conj(w) D,  Z'[M1-u] = conj(S) + i w conj(D),  S = Q[u] + conj Q[M1-u], D = Q[u] - conj Q[M1-u]
-    constexpr int NPAIRS = (M1 / 2 + 1) * H, STEPS = (NPAIRS + NT - 1) / NT;
-    if constexpr ((ASX_RABL & 2) != 0) {
-        constexpr int NE = M1 << logH, ST = (NE + NT - 1) / NT;
-        float4 v[ST];
-        static_for<0, ST>([&](auto I) __attribute__((always_inline)) {
-            const int e = threadIdx.x + decltype(I)::value * NT;
-            if (e < NE) v[I] = *reinterpret_cast<const float4 *>(in + (size_t)(e >> logH) * M2 + c0 + 2 * (e & (H - 1)));
+    // ---- first stage to run (the innermost, radix RL = R_last, RL consecutive slots per butterfly), fed from HBM --------
+    // Butterfly b of a column pair holds the frequencies u_b + MB t (t < RL, MB = M1 / RL, u_b = digit swap of b); their
+    // tangling partners M1 - u_b - MB t are element RL-1-t of butterfly b' (u_b' = MB - u_b).  A work item takes BOTH
+    // butterflies: 2 RL rows of 16 bytes straight from HBM, the tangling in registers
+    //     Z'[u] = S + i conj(w) D,  Z'[M1-u] = conj(S - i conj(w) D),  S = Q[u] + conj Q[M1-u], D = Q[u] - conj Q[M1-u], w = w_{2 M1}^u
+    // (w = w_{2 M1}^u_b times the compile-time root w_{2 RL}^t), the two inverse butterflies, 2 RL slots written: no fill
+    // phase, no index table, no barrier before the first stage.  u_b = 0 (rows 0, MB, ..., M1: the extra row is its own
+    // partner row set) and u_b = MB/2 pair with themselves: one butterfly.
+    static_assert(S1::nstages == 3, "three-stage column schedules");
+    constexpr StageK KL = S1::stage(2), KM = S1::stage(1);
+    constexpr int RL = KL.R, R0c = S1::stage(0).R, R1c = KM.R, MB = M1 / RL;
+    static_assert(KL.q == 1 && MB == R0c * R1c && MB % 2 == 0, "innermost stage of consecutive slots");
+    constexpr int NITEMS = (MB / 2) * H; // v = 0 takes both butterflies that pair with themselves (u_b = 0 and MB/2)
+    const TwPre pre_mid = tw_prefetch_exec<S1, 1, true, true, true>(Lc, P.tw1);
+    for (int e = threadIdx.x; e < NITEMS; e += NT) {
+        const int g = e & (H - 1), v = e >> logH;  // v = u_b in [0, MB/2)
+        const int ub = v, ubp = v == 0 ? MB / 2 : MB - v; // first rows of the two butterflies' row sets
+        const float2 *ca = in + (size_t)ub * M2 + c0 + 2 * g, *cb = in + (size_t)ubp * M2 + c0 + 2 * g;
+        Cx2 A[RL], B[RL];
+        static_for<0, RL>([&](auto TT) __attribute__((always_inline)) {
+            constexpr int t = decltype(TT)::value;
+            const float4 x = *reinterpret_cast<const float4 *>(ca + (size_t)(t * MB) * M2);
+            const float4 y = *reinterpret_cast<const float4 *>(cb + (size_t)(t * MB) * M2);
+            A[t] = Cx2{ v2f{ x.x, x.z }, v2f{ x.y, x.w } };
+            B[t] = Cx2{ v2f{ y.x, y.z }, v2f{ y.y, y.w } };
         });
-        static_for<0, ST>([&](auto I) __attribute__((always_inline)) {
-            const int e = threadIdx.x + decltype(I)::value * NT;
-            if (e < NE) lds4[e] = v[I];
-        });
-    } else {
-        float4 qa[STEPS], qb[STEPS];
-        int4 cps[STEPS];
-        static_for<0, STEPS>([&](auto I) __attribute__((always_inline)) {
-            const int e = threadIdx.x + decltype(I)::value * NT;
-            const int g = e & (H - 1), v = e >> logH;
-            cps[I] = PD.col_pairs[e < NPAIRS ? v : 0];
-            if (e < NPAIRS) {
-                qa[I] = *reinterpret_cast<const float4 *>(in + (size_t)cps[I].x * M2 + c0 + 2 * g);
-                qb[I] = *reinterpret_cast<const float4 *>(in + (size_t)(M1 - cps[I].x) * M2 + c0 + 2 * g);
-            }
-        });
-        static_for<0, STEPS>([&](auto I) __attribute__((always_inline)) {
-            const int e = threadIdx.x + decltype(I)::value * NT;
-            if (e < NPAIRS) {
-                const int g = e & (H - 1), v = e >> logH;
-                const float2 w = PD.col_tw[v];
-                const Cx2 a = Cx2{ v2f{ qa[I].x, qa[I].z }, v2f{ qa[I].y, qa[I].w } };
-                const Cx2 b = Cx2{ v2f{ qb[I].x, qb[I].z }, v2f{ qb[I].y, qb[I].w } };
-                const Cx2 S = Cx2{ a.re + b.re, a.im - b.im };
-                const Cx2 D = Cx2{ a.re - b.re, a.im + b.im };
-                const Cx2 t = mul_pos_i(mulwc(D, w));          // i conj(w) D
-                const Cx2 za = S + t;
-                // i w conj(D) = conj(-i conj(w) D) = -conj(t):  Z'[M1-u] = conj(S) - conj(t) = conj(S - t)
-                const Cx2 zb = S - t;
-                lds_put(lds4 + (cps[I].y << logH) + g, za);
-                if (cps[I].z != cps[I].y) lds_put(lds4 + (cps[I].z << logH) + g, Cx2{ zb.re, -zb.im });
-            }
+        Cx2 za[RL], zb[RL];
+        if (v != 0) {
+            const float2 wu = tw_F(P, (uint32_t)ub * (uint32_t)M2); // w_{2 M1}^u_b = w_F^(u_b M2)
+            static_for<0, RL>([&](auto TT) __attribute__((always_inline)) {
+                constexpr int t = decltype(TT)::value;
+                const Cx2 b = B[RL - 1 - t];
+                const Cx2 S = Cx2{ A[t].re + b.re, A[t].im - b.im };
+                const Cx2 D = Cx2{ A[t].re - b.re, A[t].im + b.im };
+                const Cx2 tt = mul_pos_i(mul_root<2 * RL, t, true>(mulwc(D, wu))); // i conj(w) D, w = wu * w_{2 RL}^t
+                za[t] = S + tt;
+                const Cx2 m = S - tt;
+                zb[RL - 1 - t] = Cx2{ m.re, -m.im };
+            });
+        } else {
+            // u_b = 0: Q[MB t] pairs with Q[MB (RL - t)], t = 0 with the extra row M1; u_b = MB/2: within the butterfly
+            const float4 xm = *reinterpret_cast<const float4 *>(in + (size_t)M1 * M2 + c0 + 2 * g);
+            const Cx2 QM = Cx2{ v2f{ xm.x, xm.z }, v2f{ xm.y, xm.w } };
+            static_for<0, RL>([&](auto TT) __attribute__((always_inline)) {
+                constexpr int t = decltype(TT)::value;
+                Cx2 b = QM;
+                if constexpr (t != 0) b = A[RL - t];
+                const Cx2 S = Cx2{ A[t].re + b.re, A[t].im - b.im };
+                const Cx2 D = Cx2{ A[t].re - b.re, A[t].im + b.im };
+                za[t] = S + mul_pos_i(mul_root<2 * RL, t, true>(D));
+            });
+            static_for<0, RL>([&](auto TT) __attribute__((always_inline)) {
+                constexpr int t = decltype(TT)::value;
+                const Cx2 b = B[RL - 1 - t];
+                const Cx2 S = Cx2{ B[t].re + b.re, B[t].im - b.im };
+                const Cx2 D = Cx2{ B[t].re - b.re, B[t].im + b.im };
+                zb[t] = S + mul_pos_i(mul_root<4 * RL, 2 * t + 1, true>(D));
+            });
+        }
+        // slots: butterfly b = d0 * R1 + d1 for u_b = d0 + R0 * d1
+        const int d1 = ub / R0c, d0 = ub - d1 * R0c, e1 = ubp / R0c, e0 = ubp - e1 * R0c;
+        float4 *pa = lds4 + (((d0 * R1c + d1) * RL) << logH) + g, *pb = lds4 + (((e0 * R1c + e1) * RL) << logH) + g;
+        Bfly<RL, true>::run(za);
+        Bfly<RL, true>::run(zb);
+        static_for<0, RL>([&](auto TT) __attribute__((always_inline)) {
+            lds_put(pa + (decltype(TT)::value << logH), za[TT]);
+            lds_put(pb + (decltype(TT)::value << logH), zb[TT]);
         });
     }
     __syncthreads();
-    const TwPre pre_last = lds_fft_static_head<S1, true, true>(lds4, Lc, P.tw1, pre);
+    const TwPre pre_last = lds_fft_static_steps<S1, true, true, S1::nstages - 1, true, 1>(lds4, Lc, P.tw1, pre_mid);
     const asx_peak_t run0 = s_run0;
     const float b2 = s_b2;
     auto last_stage = [&](auto &&sink) __attribute__((always_inline)) {
@@ -620,9 +681,11 @@ bool asx_launch_rows_r(const AsxDev &P, const float2 *cx, const float2 *cy, floa
 }
 
 // Column schedules of the production sample lengths (plan_math.cpp's tuned table):  X(M1, tile width in real columns,
-// block size, radices...)
+// block size, radices...).  (1200- and 800-row tiles hold only eight real columns: 32-byte input pieces, measured 25 % slower
+// in k_fwd_cols_r, and a fed first stage of radix 10 needs 20 rows in flight per thread: the two longest lengths use 600 / 400
+// rows with 2400-point rows instead.)
 #define ASX_RCOLS(X) \
-    X(1200, 8, 512, 12, 10, 10) X(800, 8, 320, 10, 10, 8) X(600, 16, 512, 10, 10, 6) X(400, 16, 320, 10, 8, 5) X(300, 16, 256, 10, 6, 5)
+    X(600, 16, 512, 10, 10, 6) X(400, 16, 320, 10, 8, 5) X(300, 16, 256, 10, 6, 5)
 
 static void allow_big_lds_r(const void *fn, size_t bytes)
 {

@@ -356,7 +356,7 @@ def test_two_pass_row_kernel_matches_oracle_and_default(mod, torch, monkeypatch,
         d_coef = torch.empty(batch, dtype=torch.float64, device="cuda")
         d_ret = torch.empty(batch, dtype=torch.int32, device="cuda")
         with mod.Plan(n, batch, 0) as plan:
-            assert plan.split[1] == 1200
+            assert plan.split[1] == (1200 if flag else (2400 if n >= 960000 else 1200))
             plan.xcorr_batch_dev(d_src.data_ptr(), d_smp.data_ptr(), batch, d_lag.data_ptr(), d_coef.data_ptr(),
                                  d_ret.data_ptr(), stream)
             torch.cuda.synchronize()

@@ -18,7 +18,10 @@ def test_length_and_split(n):
     M = F // 2
     assert d["M1"] * d["M2"] == M
     assert d["T"] >= 1 and d["T"] & (d["T"] - 1) == 0 and d["T"] <= 64
-    assert d["M1"] * d["T"] * 8 <= 80 * 1024 and 4 * d["M2"] * 8 <= 64 * 1024
+    # LDS: a column tile; a row block = four rows of the packed-sample kernel, or one row of each spectrum of the
+    # real-column kernel (the 2400-point rows of the two longest reference lengths, csrc/rlayout.hip)
+    assert d["M1"] * d["T"] * 8 <= 80 * 1024
+    assert 4 * d["M2"] * 8 <= 64 * 1024 or (n in (960000, 1440000) and 2 * d["M2"] * 8 <= 64 * 1024)
     assert int(np.prod(d["radix1"], dtype=np.int64)) == d["M1"]
     assert int(np.prod(d["radix2"], dtype=np.int64)) == d["M2"]
     assert set(d["radix1"] + d["radix2"]) <= {2, 3, 4, 5, 6, 8, 9, 10, 12, 15, 16}
@@ -28,7 +31,8 @@ def test_length_and_split(n):
 def test_production_lengths_are_not_embedded_and_use_wide_tiles(n):
     d = asx().planmath_describe(n)
     assert d["F"] == 2 * n          # true circular correlation of length 2N
-    assert d["T"] >= 8              # at least 64-byte row segments in the column kernels
+    assert d["T"] >= 16             # sixteen real columns per tile: 64-byte input pieces, whole lines of the intermediates
+    assert d["M1"] % 2 == 0 and d["M2"] % d["T"] == 0 and d["M2"] in (480, 1200, 2400)   # what csrc/rlayout.hip needs
 
 
 @pytest.mark.parametrize("n", [6, 30, 1000, 48000, 144000])
