@@ -176,14 +176,6 @@ static int plan_init(asx_plan *p, size_t N, size_t max_batch, const char *split)
     // the device's r is the unnormalised inverse transform: F times the plain sum of products
     d.bound_scale = 2.0f * ASX_BOUND_C * 5.9604645e-8f * log2f((float)h.F) * (float)h.F;
     d.st1 = h.st1; d.st2 = h.st2;
-    d.tw2r = nullptr;
-    d.rows2_ra = d.rows2_rb = 0;
-    // The two-pass row kernel (rows2.hip) is opt-in, ASX_ROWS2=1: measured equal to the three-pass k_rows on the
-    // headline length (1.16-1.18 ms against 1.14-1.15 ms per 124 pairs), so the default stays.
-    if (!h.tw2r.empty() && getenv("ASX_ROWS2") && atoi(getenv("ASX_ROWS2")) != 0 && !getenv("ASX_GENERIC")) {
-        d.rows2_ra = h.rows2_ra; d.rows2_rb = h.rows2_rb;
-        if (dev_upload(p, &d.tw2r, h.tw2r)) return -1;
-    }
     d.threads_cols = asx_pick_threads(h.st1, h.T / 2, 64, asx_lds_bytes_cols(d));
     d.threads_rows = asx_pick_threads(h.st2, 2, (h.M2 + ASX_ROW_STEPS - 1) / ASX_ROW_STEPS, asx_lds_bytes_rows(d));
     if (const char *e = getenv("ASX_THREADS_COLS")) d.threads_cols = atoi(e);
@@ -195,14 +187,14 @@ static int plan_init(asx_plan *p, size_t N, size_t max_batch, const char *split)
         return -1;
 
     // Which decomposition: the real-column kernels (rlayout.hip) when the plan allows them and they are compiled in for its
-    // schedules (the reference's six lengths); ASX_LAYOUT=packed forces the packed-sample kernels (A/B runs, the two-pass
-    // row kernel, the run-time-schedule kernels of ASX_GENERIC)
+    // schedules (the reference's six lengths); ASX_LAYOUT=packed forces the packed-sample kernels (A/B runs, the run-time-schedule
+    // kernels of ASX_GENERIC)
     d.rlayout = 0;
     d.col_pairs = nullptr;
     d.col_tw = nullptr;
     {
         const char *lay = getenv("ASX_LAYOUT");
-        const bool packed = (lay && !strcmp(lay, "packed")) || getenv("ASX_GENERIC") || d.rows2_ra;
+        const bool packed = (lay && !strcmp(lay, "packed")) || getenv("ASX_GENERIC");
         if (h.rlayout && !packed) {
             if (dev_upload(p, &d.col_pairs, h.col_pairs) || dev_upload(p, &d.col_tw, h.col_tw)) return -1;
             d.rlayout = asx_rlayout_available(d) ? 1 : 0;

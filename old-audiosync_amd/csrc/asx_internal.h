@@ -66,8 +66,6 @@ struct AsxDev {
     const float2 *tw1;     // w_{M1}^q, q < M1
     const float2 *tw2;     // w_{M2}^q, q < M2
     const float2 *tw2s;    // the same in slot order: tw2s[pos2_of_k2[k2]] = w_{M2}^k2
-    const float2 *tw2r;    // two-pass row kernel (rows2.hip): tw2r[u*RB + v] = w_{M2}^(u + RA*v); null if M2 has no such kernel
-    int rows2_ra, rows2_rb; // M2 = RA*RB of that kernel (0 = none)
     const float2 *tw_lo;   // w_F^q, q < 2^ASX_TW_LOG
     const float2 *tw_hi;   // w_F^(h * 2^ASX_TW_LOG)
     const int *k1_of_pos1; // row slot -> k1
@@ -128,8 +126,6 @@ void asx_launch_rows(const AsxDev &P, const float2 *zxa, const float2 *zya, floa
                      const AsxPeakWs &W, int npairs, hipStream_t s);
 void asx_launch_inv_cols(const AsxDev &P, const float2 *ga, const AsxPeakWs &W, float *r_out,
                          int npairs, hipStream_t s);
-bool asx_launch_rows2(const AsxDev &P, const float2 *zxa, const float2 *zya, float2 *ga, const AsxPeakWs &W,
-                      int npairs, hipStream_t s); // rows2.hip; false = no two-pass kernel for this row length
 // rlayout.hip: the real-column decomposition (production lengths); false = no kernel compiled in for this plan
 bool asx_launch_rows_r(const AsxDev &P, const float2 *cx, const float2 *cy, float2 *q, const AsxPeakWs &W, int npairs,
                        hipStream_t s);

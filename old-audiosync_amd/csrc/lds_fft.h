@@ -117,8 +117,8 @@ __device__ __forceinline__ v2f operator*(float b, v2f a) { return v2f{ a.x * b, 
 struct Cx2 {
     v2f re, im;
 };
-// One complex value per thread ("single member"): the two-pass row kernel (rows2.hip) runs radix-30/40
-// butterflies, whose two-member form would not fit the register file.
+// One complex value per thread ("single member"): the inverse row transforms of the real-column kernels (rlayout.hip)
+// run on the single product row X conj(Y).
 struct Cx1 {
     float re, im;
 };
@@ -307,11 +307,6 @@ template <bool INV> struct Bfly<10, INV> : BflyP<2, 5, INV> {};
 template <bool INV> struct Bfly<12, INV> : BflyP<3, 4, INV> {};
 template <bool INV> struct Bfly<15, INV> : BflyP<3, 5, INV> {};
 template <bool INV> struct Bfly<16, INV> : BflyC<4, 4, INV> {};
-// the radices of the two-pass row kernel (rows2.hip), single member only: prime-factor maps all the way down
-template <bool INV> struct Bfly<20, INV> : BflyP<4, 5, INV> {};
-template <bool INV> struct Bfly<24, INV> : BflyP<3, 8, INV> {};
-template <bool INV> struct Bfly<30, INV> : BflyP<5, 6, INV> {};
-template <bool INV> struct Bfly<40, INV> : BflyP<5, 8, INV> {};
 
 // ---------------------------------------------------------------------------
 // One stage.  The LDS image is an array of float4 slots; slot (g, e) = element e of the

@@ -209,7 +209,7 @@ std::string asx_host_plan_build(size_t N, const char *split_override, AsxHostPla
     };
     if (!(split_override && *split_override)) {
         const char *lay = getenv("ASX_LAYOUT");
-        const bool packed = (lay && !strcmp(lay, "packed")) || getenv("ASX_GENERIC") || (getenv("ASX_ROWS2") && atoi(getenv("ASX_ROWS2")) != 0);
+        const bool packed = (lay && !strcmp(lay, "packed")) || getenv("ASX_GENERIC");
         for (const auto &t : kTuned)
             if (t.M == M && F == 2 * (uint64_t)N) split_override = (packed && t.split_packed) ? t.split_packed : t.split;
     }
@@ -278,18 +278,6 @@ std::string asx_host_plan_build(size_t N, const char *split_override, AsxHostPla
         if (hp->pos2_of_k2[M2 - 1 - k2] != M2 - 1 - hp->pos2_of_k2[k2]) return "position table is not a digit reversal";
         hp->tw2s[hp->pos2_of_k2[k2]] = hp->tw2[k2];
     }
-    // Row lengths with a two-pass kernel (rows2.hip): M2 = RA*RB, bin k2 = u + RA*v lives at slot (u, v).
-    hp->tw2r.clear();
-    hp->rows2_ra = hp->rows2_rb = 0;
-    static const struct { int m2, ra, rb; } kRows2[] = { { 1200, 30, 40 } };
-    for (auto c : kRows2)
-        if (c.m2 == M2) {
-            if (getenv("ASX_ROWS2_SWAP")) std::swap(c.ra, c.rb); // diagnostic: the factors the other way round
-            hp->rows2_ra = c.ra; hp->rows2_rb = c.rb;
-            hp->tw2r.resize(M2);
-            for (int u = 0; u < c.ra; u++)
-                for (int v = 0; v < c.rb; v++) hp->tw2r[u * c.rb + v] = unit_root((uint64_t)(u + c.ra * v), M2);
-        }
     hp->row_tasks.resize(M1 / 2 + 1);
     for (int k1 = 0; k1 <= M1 / 2; k1++) {
         const int m1 = (M1 - k1) % M1;

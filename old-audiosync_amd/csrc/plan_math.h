@@ -15,8 +15,6 @@ struct AsxHostPlan {
     int M1 = 0, M2 = 0, T = 0, logT = 0, ntiles = 0;
     AsxStages st1{}, st2{};
     std::vector<float2> tw1, tw2, tw2s, tw_lo, tw_hi;
-    std::vector<float2> tw2r;       // two-pass row kernel: w_M2^(u + RA*v) at u*RB + v (empty: no such kernel for M2)
-    int rows2_ra = 0, rows2_rb = 0; // its factors, M2 = RA*RB
     std::vector<int> k1_of_pos1, pos1_of_k1, pos2_of_k2;
     std::vector<int4> row_tasks;
     // real-column decomposition (rlayout.hip): possible when M1 is even, the length is not embedded and tiles are whole

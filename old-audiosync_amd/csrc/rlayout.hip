@@ -101,7 +101,7 @@ __global__ __launch_bounds__(TWO ? 2 * NT : NT, ASX_ROWSR_WAVES) void k_rows_r(c
     const int half = TWO ? tid / NT : 0, lt = tid - half * NT; // which sub-row, thread index inside its half
     float4 *A4 = reinterpret_cast<float4 *>(asx_lds_r) + half * NS;
     __shared__ float2 tw_step[WSTEPS]; // (1/2) w_F^(k1 * 2*NTB*i): the four-step twiddle from load step to load step
-    __shared__ float2 leg[R0];         // w_F^(k1 * Q0*t): ... and from leg to leg of the last inverse stage (!TWO)
+    __shared__ float2 leg[R0];         // w_F^(k1 * Q0*t): ... and from leg to leg of the last inverse stage
 
     const int pair = task / nrows;
     const uint32_t k1 = (uint32_t)(task - pair * nrows);
@@ -140,14 +140,14 @@ __global__ __launch_bounds__(TWO ? 2 * NT : NT, ASX_ROWSR_WAVES) void k_rows_r(c
         const float2 t = tw_F(P, k1 * (uint32_t)(2 * NTB * tid));
         tw_step[tid] = make_float2(0.5f * t.x, 0.5f * t.y);
     }
-    if (!TWO && tid >= NTB - R0) { const int t = tid - (NTB - R0); leg[t] = tw_F(P, k1 * (uint32_t)(Q0 * t)); }
+    if (tid >= NTB - R0) { const int t = tid - (NTB - R0); leg[t] = tw_F(P, k1 * (uint32_t)(Q0 * t)); }
     const float2 twa = tw_F(P, k1 * (uint32_t)(2 * tid < NS ? 2 * tid : 0)); // w_F^(k1 * 2 tid)
     const float2 wk1 = tw_F(P, k1);
     const float2 wh = TWO ? tw_F(P, k1 * (uint32_t)NS) : make_float2(1.f, 0.f); // w_F^(k1 n): from c[j] to c[j + n]
     // stage twiddle seeds (they depend on the thread only): stage 0 / inverse stage 0, and the wave-local stage 1
     const int j0 = lt < Q0 ? lt : 0;
     const float2 s0w1 = P.tw2[TWS * j0], s0w4 = P.tw2[TWS * 4 * j0];
-    const float2 tw0base = TWO ? make_float2(1.f, 0.f) : tw_F(P, k1 * (uint32_t)j0); // four-step factor of the outputs of inverse stage 0
+    const float2 tw0base = TWO ? make_float2(1.f, 0.f) : tw_F(P, k1 * (uint32_t)j0); // four-step factor of the outputs of inverse stage 0 (!TWO)
     const int lane = tid & 63, wave = lt >> 6;
     const int ul = lane / LPU, jl = lane - ul * LPU;
     const int j1c = jl < R2 ? jl : 0;
@@ -234,51 +234,57 @@ __global__ __launch_bounds__(TWO ? 2 * NT : NT, ASX_ROWSR_WAVES) void k_rows_r(c
     }
     __syncthreads();
 
-    // ---- inverse stage 0 from LDS -----------------------------------------------------------------------------
+    // ---- inverse stage 0 from LDS, the outputs leave from registers -------------------------------------------------
     float2 *go = qo + row;
-    for (int j = lt; j < Q0; j += NT) {
-        float4 *p = A4 + j;
-        Cx1 v[R0];
-        static_for<0, R0>([&](auto T) __attribute__((always_inline)) { v[T] = lds_get1(p + decltype(T)::value * Q0); });
-        float2 w1 = s0w1, w4 = s0w4, fb = tw0base;
-        if (j != lt) { w1 = P.tw2[TWS * j]; w4 = P.tw2[TWS * 4 * j]; if (!TWO) fb = tw_F(P, k1 * (uint32_t)j); }
-        float2 tww[R0];
-        stage_twiddles_from<R0>(w1, w4, tww);
-        static_for<1, R0>([&](auto U) __attribute__((always_inline)) { v[U] = mulwc(v[U], tww[U]); });
-        Bfly<R0, true>::run(v);
-        if constexpr (!TWO) {
+    if constexpr (!TWO) {
+        for (int j = lt; j < Q0; j += NT) {
+            const float4 *p = A4 + j;
+            Cx1 v[R0];
+            static_for<0, R0>([&](auto T) __attribute__((always_inline)) { v[T] = lds_get1(p + decltype(T)::value * Q0); });
+            float2 w1 = s0w1, w4 = s0w4, fb = tw0base;
+            if (j != lt) { w1 = P.tw2[j]; w4 = P.tw2[4 * j]; fb = tw_F(P, k1 * (uint32_t)j); }
+            float2 tww[R0];
+            stage_twiddles_from<R0>(w1, w4, tww);
+            static_for<1, R0>([&](auto U) __attribute__((always_inline)) { v[U] = mulwc(v[U], tww[U]); });
+            Bfly<R0, true>::run(v);
             // conjugate four-step twiddle, straight to HBM
             static_for<0, R0>([&](auto T) __attribute__((always_inline)) {
                 constexpr int t = decltype(T)::value;
                 const Cx1 y = mulwc(v[t], t == 0 ? fb : cmul(fb, leg[t]));
                 go[j + t * Q0] = make_float2(y.re, y.im);
             });
-        } else {
-            static_for<0, R0>([&](auto T) __attribute__((always_inline)) { lds_put1(p + decltype(T)::value * Q0, v[T]); });
         }
-    }
-    if constexpr (TWO) {
-        // the last radix-2 stage of the inverse, the conjugate four-step twiddle, 16 bytes per lane to HBM
-        __syncthreads();
+    } else {
+        // Both halves at once, as ONE pair of sequences (A, B) per thread: the butterfly j of inverse stage 0 of the
+        // even-bin and of the odd-bin problem share their twiddles, and their outputs A[j + Q0 t], B[j + Q0 t] are exactly
+        // what the last radix-2 stage combines:  Q[i] = A[i] + conj(w_M2^i) B[i],  Q[i + n] = A[i] - conj(w_M2^i) B[i]
+        // (w_M2^(j + Q0 t) = w_M2^j times the compile-time root w_{2 R0}^t), then the conjugate four-step twiddles.
+        // Only Q0 threads work here; the others are done.
         const float4 *base = reinterpret_cast<const float4 *>(asx_lds_r);
-        static_for<0, WSTEPS>([&](auto I) __attribute__((always_inline)) {
-            constexpr int i = decltype(I)::value;
-            const int q = tid + i * NTB;
-            if (q < HALF) {
-                const Cx1 a0 = lds_get1(base + 2 * q), a1 = lds_get1(base + 2 * q + 1);
-                const Cx1 b0 = lds_get1(base + NS + 2 * q), b1 = lds_get1(base + NS + 2 * q + 1);
-                const float4 w2 = *reinterpret_cast<const float4 *>(P.tw2 + 2 * q);
-                const Cx1 t0 = mulwc(b0, make_float2(w2.x, w2.y)), t1 = mulwc(b1, make_float2(w2.z, w2.w));
-                // (tw_step carries the factor 1/2 of the load phase: taken out again with the factor 2)
-                const float2 ws = tw_step[i];
-                const float2 wa0 = cmul(twa, make_float2(2.f * ws.x, 2.f * ws.y)), wa1 = cmul(wa0, wk1);
-                const float2 wb0 = cmul(wa0, wh), wb1 = cmul(wa1, wh);
-                const Cx1 y0 = mulwc(a0 + t0, wa0), y1 = mulwc(a1 + t1, wa1);
-                const Cx1 z0 = mulwc(a0 - t0, wb0), z1 = mulwc(a1 - t1, wb1);
-                *reinterpret_cast<float4 *>(go + 2 * q) = make_float4(y0.re, y0.im, y1.re, y1.im);
-                *reinterpret_cast<float4 *>(go + NS + 2 * q) = make_float4(z0.re, z0.im, z1.re, z1.im);
-            }
-        });
+        for (int j = tid; j < Q0; j += NTB) {
+            Cx2 v[R0];
+            static_for<0, R0>([&](auto T) __attribute__((always_inline)) {
+                const Cx1 a = lds_get1(base + j + decltype(T)::value * Q0), b = lds_get1(base + NS + j + decltype(T)::value * Q0);
+                v[T] = Cx2{ v2f{ a.re, b.re }, v2f{ a.im, b.im } };
+            });
+            float2 tww[R0];
+            stage_twiddles_from<R0>(P.tw2[TWS * j], P.tw2[TWS * 4 * j], tww);
+            static_for<1, R0>([&](auto U) __attribute__((always_inline)) { v[U] = mulwc(v[U], tww[U]); });
+            Bfly<R0, true>::run(v);
+            const float2 w2 = P.tw2[j];                       // w_M2^j
+            const float2 fa = tw_F(P, k1 * (uint32_t)j);      // w_F^(k1 j)
+            const float2 fbh = cmul(fa, wh);                  // w_F^(k1 (j + n))
+            static_for<0, R0>([&](auto T) __attribute__((always_inline)) {
+                constexpr int t = decltype(T)::value;
+                const Cx1 A = Cx1{ v[t].re.x, v[t].im.x };
+                const Cx1 Bw = mul_root<2 * R0, t, true>(mulwc(Cx1{ v[t].re.y, v[t].im.y }, w2)); // conj(w_M2^(j + Q0 t)) B
+                const float2 lg = leg[t];
+                const Cx1 y = mulwc(A + Bw, t == 0 ? fa : cmul(fa, lg));
+                const Cx1 z = mulwc(A - Bw, t == 0 ? fbh : cmul(fbh, lg));
+                go[j + t * Q0] = make_float2(y.re, y.im);
+                go[NS + j + t * Q0] = make_float2(z.re, z.im);
+            });
+        }
     }
 }
 

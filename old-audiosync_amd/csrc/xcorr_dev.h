@@ -1,4 +1,4 @@
-// csrc/xcorr_dev.h -- device helpers shared by the kernel translation units (xcorr_kernels.hip, rows2.hip).
+// csrc/xcorr_dev.h -- device helpers shared by the kernel translation units (xcorr_kernels.hip, rlayout.hip).
 #pragma once
 
 #include "asx_internal.h"

@@ -1489,7 +1489,6 @@ void asx_launch_rows(const AsxDev &P, const float2 *zxa, const float2 *zya, floa
                      const AsxPeakWs &W, int npairs, hipStream_t s)
 {
     if (P.rlayout && asx_launch_rows_r(P, zxa, zya, ga, W, npairs, s)) return;
-    if (!generic_only() && asx_launch_rows2(P, zxa, zya, ga, W, npairs, s)) return; // two LDS passes per transform
     if (generic_only() || !asx_launch_rows_static(P, zxa, zya, ga, W, npairs, s))
         asx_launch_rows_generic(P, zxa, zya, ga, W, npairs, s);
 }

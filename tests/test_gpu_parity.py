@@ -335,40 +335,6 @@ def test_full_size_planted_delay_and_oracle(mod, torch):
     assert o_ret == 0 and o_lag == int(d_lag[0]) and abs(o_coef - float(d_coef[0])) < COEF_TOL
 
 
-@pytest.mark.parametrize("n", [480000, 1440000])
-def test_two_pass_row_kernel_matches_oracle_and_default(mod, torch, monkeypatch, n):
-    """ASX_ROWS2=1 (read when a plan is created) selects k_rows2 (csrc/rows2.hip): the row kernel with one LDS exchange
-    per transform (1200 = 30 x 40, radix-30 / radix-40 butterflies) instead of three passes.  Same answers as the
-    default k_rows and as the oracle."""
-    batch = 4
-    d_src = torch.empty(batch * 2 * n, dtype=torch.float32, device="cuda")
-    d_smp = torch.empty(batch * n, dtype=torch.float32, device="cuda")
-    d_true = torch.empty(batch, dtype=torch.int64, device="cuda")
-    stream = torch.cuda.current_stream().cuda_stream
-    mod.synth_pairs_dev(777, 0, batch, n, 0, d_src.data_ptr(), d_smp.data_ptr(), d_true.data_ptr(), stream)
-    got = {}
-    for label, flag in (("default", None), ("rows2", "1")):
-        if flag is None:
-            monkeypatch.delenv("ASX_ROWS2", raising=False)
-        else:
-            monkeypatch.setenv("ASX_ROWS2", flag)
-        d_lag = torch.empty(batch, dtype=torch.int64, device="cuda")
-        d_coef = torch.empty(batch, dtype=torch.float64, device="cuda")
-        d_ret = torch.empty(batch, dtype=torch.int32, device="cuda")
-        with mod.Plan(n, batch, 0) as plan:
-            assert plan.split[1] == (1200 if flag else (2400 if n >= 960000 else 1200))
-            plan.xcorr_batch_dev(d_src.data_ptr(), d_smp.data_ptr(), batch, d_lag.data_ptr(), d_coef.data_ptr(),
-                                 d_ret.data_ptr(), stream)
-            torch.cuda.synchronize()
-            assert plan.peak_overflows() == 0
-        assert torch.equal(d_lag, d_true) and int(d_ret.abs().sum()) == 0
-        got[label] = d_coef.cpu().numpy()
-    assert np.max(np.abs(got["default"] - got["rows2"])) < 1e-12   # same lag, same float64 Pearson pass
-    src = d_src[: 2 * n].cpu().numpy(); smp = d_smp[:n].cpu().numpy()
-    o_ret, o_lag, o_coef = oracle.cross_correlation(src, smp)
-    assert o_ret == 0 and o_lag == int(d_true[0]) and abs(o_coef - float(got["rows2"][0])) < COEF_TOL
-
-
 # ---- growing-window (streaming) mode: BASELINE config 5 --------------------------------------
 
 def test_stream_growing_window_matches_oracle(mod):

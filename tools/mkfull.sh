@@ -13,10 +13,9 @@ for p in 1 2 4 8 16 32 64; do
   /opt/rocm/bin/hipcc $F $kf $flags -DASX_PART=$p -c -o $D/k$p.o $P/csrc/xcorr_kernels.hip &
   objs="$objs $D/k$p.o"
 done
-/opt/rocm/bin/hipcc $F $flags -c -o $D/rows2.o $P/csrc/rows2.hip &
 /opt/rocm/bin/hipcc $F -mllvm -amdgpu-sched-strategy=iterative-ilp $flags -c -o $D/rlayout.o $P/csrc/rlayout.hip &
 /opt/rocm/bin/hipcc $F $flags -c -o $D/api.o $P/csrc/asx_api.hip &
 /opt/rocm/bin/hipcc $F $flags -c -o $D/plan.o $P/csrc/plan_math.cpp &
 wait
-/opt/rocm/bin/hipcc -fPIC --offload-arch=gfx950 -shared -o $R/ab/$name.so $D/api.o $D/plan.o $D/rows2.o $D/rlayout.o $objs -ldl
+/opt/rocm/bin/hipcc -fPIC --offload-arch=gfx950 -shared -o $R/ab/$name.so $D/api.o $D/plan.o $D/rlayout.o $objs -ldl
 echo "ab/$name.so"
