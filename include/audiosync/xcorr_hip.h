@@ -98,6 +98,10 @@ size_t asx_plan_peak_capacity(const asx_plan *plan);
 size_t asx_plan_sample_len(const asx_plan *plan);
 size_t asx_plan_fft_len(const asx_plan *plan);        /* F, real transform length */
 int asx_plan_split(const asx_plan *plan, int *m1, int *m2, int *tile_cols);
+/* Which decomposition the plan runs: 1 = the real-column kernels (csrc/rlayout.hip: r2c / c2r column transforms with the
+ * untangling inside the tile, one independent row problem per k1; the reference's six lengths), 0 = the packed-sample
+ * kernels (csrc/xcorr_kernels.hip: any length; forced by $ASX_LAYOUT=packed), -1 = NULL plan.  Same results either way. */
+int asx_plan_layout(const asx_plan *plan);
 int asx_plan_threads(const asx_plan *plan, int *threads_cols, int *threads_rows); /* block sizes */
 size_t asx_plan_group(const asx_plan *plan);          /* pairs per launch group */
 size_t asx_plan_workspace_bytes(const asx_plan *plan);
@@ -150,7 +154,8 @@ int asx_xcorr_batch_multi(asx_plan *const *plans, int nplans, const float *sourc
  *   asx_xcorr_batch_multi_dev(comm, d_source, d_sample, counts, width, d_gathered)
  *                       shard i = counts[i] <= width pairs resident on plans[i]'s device (d_source[i]: counts[i] * 2N
  *                       floats, d_sample[i]: counts[i] * N).  Every device runs its shard on its plan's stream from
- *                       its own host thread, then the shards' result records -- asx_result_bytes(width) bytes each:
+ *                       its own host thread, then the shards' result records -- asx_result_bytes(width) bytes each
+ *                       (20 * width rounded up to a multiple of 8, so that every record starts 8-byte aligned):
  *                       int64 lag[width] | double coef[width] | int32 ret[width], entries past counts[i] zero --
  *                       are all-gathered over xGMI: d_gathered[i] (device i, nplans * asx_result_bytes(width)
  *                       bytes) receives the record of every shard, in shard order.  Returns after all streams

@@ -5,6 +5,7 @@
 
 #include "asx_internal.h"
 #include "plan_math.h"
+#include "shard_driver.h"
 
 #include <algorithm>
 #include <cstdarg>
@@ -227,7 +228,7 @@ static int plan_init(asx_plan *p, size_t N, size_t max_batch, const char *split)
             dev_alloc(p, &ln.pk.cand, g * cap) || dev_alloc(p, &ln.pk.refine_n, g) ||
             dev_alloc(p, &ln.pk.refine_idx, g * cap) || dev_alloc(p, &ln.pk.refine_val, g * cap) ||
             dev_alloc(p, &ln.pk.overflows, 1) ||
-            dev_alloc(p, &ln.seg, g) || dev_alloc(p, &ln.psums, std::max(g * ASX_PEARSON_BLOCKS, (size_t)ASX_PEARSON_BLOCKS_MAX) * 6))
+            dev_alloc(p, &ln.seg, g) || dev_alloc(p, &ln.psums, g * (size_t)asx_pearson_blocks((uint32_t)N) * 6))
             return -1;
         HIP_TRY(hipMemset(ln.pk.overflows, 0, sizeof(unsigned long long)));
         HIP_TRY(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
@@ -471,6 +472,8 @@ extern "C" int asx_plan_threads(const asx_plan *p, int *cols, int *rows)
     return 0;
 }
 
+extern "C" int asx_plan_layout(const asx_plan *p) { return p ? p->dev.rlayout : -1; }
+
 extern "C" int asx_plan_split(const asx_plan *p, int *m1, int *m2, int *tile_cols)
 {
     if (!p) return -1;
@@ -538,10 +541,10 @@ static int run_group(asx_plan *p, const float *d_src, const float *d_smp, const 
     if (prof_mark(p, s, e0 + 4)) return -1;
     if (sizeof(TIn) == sizeof(float))
         asx_launch_pearson_f32((const float *)p_src, (const float *)p_smp, 2 * (size_t)P.N, P.N, P.N,
-                               W.seg, W.psums, std::max(p->group * ASX_PEARSON_BLOCKS, (size_t)ASX_PEARSON_BLOCKS_MAX), d_lag, d_coef, d_ret, (int)g, s);
+                               W.seg, W.psums, d_lag, d_coef, d_ret, (int)g, s);
     else
         asx_launch_pearson_f64((const double *)p_src, (const double *)p_smp, 2 * (size_t)P.N, P.N, P.N,
-                               W.seg, W.psums, std::max(p->group * ASX_PEARSON_BLOCKS, (size_t)ASX_PEARSON_BLOCKS_MAX), d_lag, d_coef, d_ret, (int)g, s);
+                               W.seg, W.psums, d_lag, d_coef, d_ret, (int)g, s);
     if (prof_mark(p, s, e0 + 5)) return -1;
     HIP_TRY(hipGetLastError());
     return 0;
@@ -579,7 +582,7 @@ static int second_look(asx_plan *p, size_t i, const float *f_smp, const TIn *p_s
         T.cap = 2 * N;
         if (dev_alloc(p, &T.cand, T.cap) || dev_alloc(p, &T.refine_idx, T.cap) || dev_alloc(p, &T.refine_val, T.cap) ||
             dev_alloc(p, &T.cand_n, 1) || dev_alloc(p, &T.refine_n, 1) || dev_alloc(p, &T.overflows, 1) ||
-            dev_alloc(p, &T.src_dc, 2 * N) || dev_alloc(p, &T.stats, 3))
+            dev_alloc(p, &T.src_dc, 2 * N) || dev_alloc(p, &T.stats, ASX_DC_STATS_DOUBLES))
             return -1;
         HIP_TRY(hipMemsetAsync(T.overflows, 0, sizeof(unsigned long long), s));
         B = T;
@@ -605,14 +608,12 @@ static int second_look(asx_plan *p, size_t i, const float *f_smp, const TIn *p_s
         asx_launch_refine_f32(P, (const float *)p_src + i * 2 * N, (const float *)p_smp + i * N, K, W.seg, 1, s, 2048);
     else
         asx_launch_refine_f64(P, (const double *)p_src + i * 2 * N, (const double *)p_smp + i * N, K, W.seg, 1, s, 2048);
-    // (the partial-block count of this one-pair launch differs from the batch's: the last bits of the coefficient
-    //  depend on the merge tree, see the numeric contract in DESIGN.md)
     if (sizeof(TIn) == sizeof(float))
         asx_launch_pearson_f32((const float *)p_src + i * 2 * N, (const float *)p_smp + i * N, 2 * N, N, P.N,
-                               W.seg, W.psums, ASX_PEARSON_BLOCKS, d_lag ? d_lag + i : nullptr, d_coef + i, d_ret ? d_ret + i : nullptr, 1, s);
+                               W.seg, W.psums, d_lag ? d_lag + i : nullptr, d_coef + i, d_ret ? d_ret + i : nullptr, 1, s);
     else
         asx_launch_pearson_f64((const double *)p_src + i * 2 * N, (const double *)p_smp + i * N, 2 * N, N, P.N,
-                               W.seg, W.psums, ASX_PEARSON_BLOCKS, d_lag ? d_lag + i : nullptr, d_coef + i, d_ret ? d_ret + i : nullptr, 1, s);
+                               W.seg, W.psums, d_lag ? d_lag + i : nullptr, d_coef + i, d_ret ? d_ret + i : nullptr, 1, s);
     HIP_TRY(hipGetLastError());
     p->repaired++;
     return 0;
@@ -785,7 +786,7 @@ extern "C" int asx_shard_range(size_t total, int nshards, int shard, size_t *sta
     return 0;
 }
 
-extern "C" size_t asx_result_bytes(size_t width) { return width * (sizeof(int64_t) + sizeof(double) + sizeof(int32_t)); }
+extern "C" size_t asx_result_bytes(size_t width) { return asx_shard_record_bytes(width); }
 
 namespace {
 typedef void *nccl_comm_t;
@@ -832,10 +833,68 @@ const Rccl *rccl_load()
 
 struct asx_comm {
     std::vector<asx_plan *> plans;
+    std::vector<int> devices;      // the plans' devices, kept here: destroy must not need the plans (they may be gone)
     std::vector<nccl_comm_t> comms;
-    std::vector<void *> local;     // per device: the shard's result record (asx_result_bytes(width) bytes)
-    size_t width = 0;
+    AsxShardState state;           // the shards' result records and the width they are sized for (shard_driver.h)
 };
+
+// the ops table of csrc/shard_driver.cpp bound to HIP + RCCL
+namespace {
+int shard_alloc(void *ctx, int i, size_t bytes, void **out, std::string *err)
+{
+    asx_comm *c = (asx_comm *)ctx;
+    DevGuard dg(c->devices[(size_t)i]);
+    if (!dg.ok) { *err = "cannot select the device"; return -1; }
+    const hipError_t e = hipMalloc(out, bytes);
+    if (e != hipSuccess) { *out = nullptr; *err = hipGetErrorString(e); return -1; }
+    return 0;
+}
+void shard_free(void *ctx, int i, void *rec)
+{
+    asx_comm *c = (asx_comm *)ctx;
+    DevGuard dg(c->devices[(size_t)i]);
+    (void)hipFree(rec);
+}
+int shard_run(void *ctx, int i, void *record, size_t width, size_t count, const float *d_src, const float *d_smp, std::string *err)
+{
+    asx_comm *c = (asx_comm *)ctx;
+    asx_plan *p = c->plans[(size_t)i];
+    if (hipSetDevice(p->device) != hipSuccess) { *err = "hipSetDevice failed"; return -1; }
+    char *base = (char *)record;
+    int64_t *lag = (int64_t *)base;
+    double *coef = (double *)(base + width * sizeof(int64_t));
+    int32_t *ret = (int32_t *)(base + width * (sizeof(int64_t) + sizeof(double)));
+    if (hipMemsetAsync(base, 0, asx_shard_record_bytes(width), p->stream) != hipSuccess) { *err = "hipMemsetAsync failed"; return -1; }
+    if (count && asx_xcorr_batch_f32_dev(p, d_src, d_smp, count, lag, coef, ret, p->stream) != 0) { *err = asx_last_error(); return -1; }
+    return 0;
+}
+int shard_gather(void *ctx, int n, void *const *records, void *const *gathered, size_t rec, std::string *err)
+{
+    asx_comm *c = (asx_comm *)ctx;
+    const Rccl *R = rccl_load();
+    if (!R) { *err = asx_last_error(); return -1; }
+    int grc = R->GroupStart();
+    for (int i = 0; i < n && grc == 0; i++) {
+        asx_plan *p = c->plans[(size_t)i];
+        DevGuard dg(p->device);
+        grc = R->AllGather(records[i], gathered[i], rec, 0 /* ncclInt8 / ncclChar */, c->comms[(size_t)i], p->stream);
+    }
+    const int erc = R->GroupEnd();
+    if (grc == 0) grc = erc;
+    if (grc != 0) { *err = R->GetErrorString(grc); return -1; }
+    return 0;
+}
+int shard_sync(void *ctx, int i, std::string *err)
+{
+    asx_comm *c = (asx_comm *)ctx;
+    asx_plan *p = c->plans[(size_t)i];
+    DevGuard dg(p->device);
+    const hipError_t e = hipStreamSynchronize(p->stream);
+    if (e != hipSuccess) { *err = hipGetErrorString(e); return -1; }
+    return 0;
+}
+AsxShardOps shard_ops(asx_comm *c) { return AsxShardOps{ c, shard_alloc, shard_free, shard_run, shard_gather, shard_sync }; }
+} // namespace
 
 extern "C" void asx_comm_destroy(asx_comm *c)
 {
@@ -843,12 +902,12 @@ extern "C" void asx_comm_destroy(asx_comm *c)
     const Rccl *R = g_rccl.handle ? &g_rccl : nullptr;
     int prev = 0;
     (void)hipGetDevice(&prev);
-    for (size_t i = 0; i < c->plans.size(); i++) {
-        (void)hipSetDevice(c->plans[i]->device);
+    for (size_t i = 0; i < c->devices.size(); i++) {
+        (void)hipSetDevice(c->devices[i]);
         if (i < c->comms.size() && c->comms[i] && R) (void)R->CommDestroy(c->comms[i]);
-        if (i < c->local.size() && c->local[i]) (void)hipFree(c->local[i]);
     }
     (void)hipSetDevice(prev);
+    asx_shard_release(shard_ops(c), c->state); // frees by device id: the plans are not touched
     delete c;
 }
 
@@ -865,10 +924,9 @@ extern "C" asx_comm *asx_comm_create(asx_plan *const *plans, int nplans)
     asx_comm *c = new asx_comm();
     c->plans.assign(plans, plans + nplans);
     c->comms.assign((size_t)nplans, nullptr);
-    c->local.assign((size_t)nplans, nullptr);
-    std::vector<int> devs((size_t)nplans);
-    for (int i = 0; i < nplans; i++) devs[(size_t)i] = plans[i]->device;
-    const int rc = R->CommInitAll(c->comms.data(), nplans, devs.data());
+    c->devices.resize((size_t)nplans);
+    for (int i = 0; i < nplans; i++) c->devices[(size_t)i] = plans[i]->device;
+    const int rc = R->CommInitAll(c->comms.data(), nplans, c->devices.data());
     if (rc != 0) {
         fail("ncclCommInitAll over %d device(s) failed: %s", nplans, R->GetErrorString(rc));
         c->comms.assign((size_t)nplans, nullptr);
@@ -881,63 +939,11 @@ extern "C" asx_comm *asx_comm_create(asx_plan *const *plans, int nplans)
 extern "C" int asx_xcorr_batch_multi_dev(asx_comm *c, const float *const *d_source, const float *const *d_sample,
                                          const size_t *counts, size_t width, void *const *d_gathered)
 {
-    if (!c || !d_source || !d_sample || !counts || !d_gathered || width == 0) return fail("asx_xcorr_batch_multi_dev: bad argument");
-    const Rccl *R = rccl_load();
-    if (!R) return -1;
-    const int n = (int)c->plans.size();
-    for (int i = 0; i < n; i++)
-        if (counts[i] > width || (counts[i] && (!d_source[i] || !d_sample[i])) || !d_gathered[i])
-            return fail("asx_xcorr_batch_multi_dev: shard %d: count %zu over width %zu, or a null pointer", i, counts[i], width);
-    const size_t rec = asx_result_bytes(width);
-    if (width != c->width) { // the shards' own result records, (re)sized to the width in use
-        c->width = 0; // a failure half-way leaves no record that the next call would take for a sized one
-        for (int i = 0; i < n; i++) {
-            DevGuard dg(c->plans[(size_t)i]->device);
-            if (!dg.ok) return fail("cannot select device %d", c->plans[(size_t)i]->device);
-            if (c->local[(size_t)i]) { (void)hipFree(c->local[(size_t)i]); c->local[(size_t)i] = nullptr; }
-            HIP_TRY(hipMalloc(&c->local[(size_t)i], rec));
-        }
-        c->width = width;
-    }
-    std::vector<int> rc((size_t)n, 0);
-    std::vector<std::string> err((size_t)n);
-    // phase 1: every device its shard, from its own host thread, on its plan's stream (asynchronous)
-    {
-        std::vector<std::thread> workers;
-        for (int i = 0; i < n; i++) {
-            workers.emplace_back([=, &rc, &err]() {
-                asx_plan *p = c->plans[(size_t)i];
-                if (hipSetDevice(p->device) != hipSuccess) { rc[(size_t)i] = -1; err[(size_t)i] = "hipSetDevice failed"; return; }
-                char *base = (char *)c->local[(size_t)i];
-                int64_t *lag = (int64_t *)base;
-                double *coef = (double *)(base + width * sizeof(int64_t));
-                int32_t *ret = (int32_t *)(base + width * (sizeof(int64_t) + sizeof(double)));
-                if (hipMemsetAsync(base, 0, rec, p->stream) != hipSuccess) { rc[(size_t)i] = -1; err[(size_t)i] = "hipMemsetAsync failed"; return; }
-                if (counts[i]) {
-                    rc[(size_t)i] = asx_xcorr_batch_f32_dev(p, d_source[i], d_sample[i], counts[i], lag, coef, ret, p->stream);
-                    if (rc[(size_t)i] != 0) err[(size_t)i] = asx_last_error();
-                }
-            });
-        }
-        for (std::thread &t : workers) t.join();
-    }
-    for (int i = 0; i < n; i++)
-        if (rc[(size_t)i] != 0) return fail("asx_xcorr_batch_multi_dev: shard %d: %s", i, err[(size_t)i].c_str());
-    // phase 2: ONE all-gather of the records, enqueued behind the kernels on the same streams (a group call: one thread
-    // drives every rank of the in-process communicator)
-    int grc = R->GroupStart();
-    for (int i = 0; i < n && grc == 0; i++) {
-        asx_plan *p = c->plans[(size_t)i];
-        DevGuard dg(p->device);
-        grc = R->AllGather(c->local[(size_t)i], d_gathered[i], rec, 0 /* ncclInt8 / ncclChar */, c->comms[(size_t)i], p->stream);
-    }
-    const int erc = R->GroupEnd();
-    if (grc == 0) grc = erc;
-    if (grc != 0) return fail("ncclAllGather of the result records failed: %s", R->GetErrorString(grc));
-    for (int i = 0; i < n; i++) {
-        DevGuard dg(c->plans[(size_t)i]->device);
-        HIP_TRY(hipStreamSynchronize(c->plans[(size_t)i]->stream));
-    }
+    if (!c) return fail("asx_xcorr_batch_multi_dev: bad argument");
+    if (!rccl_load()) return -1;
+    std::string err;
+    if (asx_shard_drive(shard_ops(c), c->state, (int)c->plans.size(), d_source, d_sample, counts, width, d_gathered, &err) != 0)
+        return fail("asx_xcorr_batch_multi_dev: %s", err.c_str());
     return 0;
 }
 
@@ -1038,7 +1044,7 @@ extern "C" int asx_pearson_f64(const double *a, const double *b, size_t n, int d
     HIP_TRY(hipMemcpyAsync(S.a, a, n * sizeof(double), hipMemcpyHostToDevice, S.stream));
     HIP_TRY(hipMemcpyAsync(S.b, b, n * sizeof(double), hipMemcpyHostToDevice, S.stream));
     HIP_TRY(hipMemcpyAsync(S.seg, &seg, sizeof(seg), hipMemcpyHostToDevice, S.stream));
-    asx_launch_pearson_f64(S.a, S.b, 0, 0, (uint32_t)n, S.seg, S.ps, ASX_PEARSON_BLOCKS_MAX, nullptr, S.c, nullptr, 1, S.stream);
+    asx_launch_pearson_f64(S.a, S.b, 0, 0, (uint32_t)n, S.seg, S.ps, nullptr, S.c, nullptr, 1, S.stream);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out, S.c, sizeof(double), hipMemcpyDeviceToHost, S.stream));
     HIP_TRY(hipStreamSynchronize(S.stream));

@@ -20,8 +20,8 @@
 #define ASX_FFT_THREADS_MAX 512             // upper bound for the three transform kernels
 #define ASX_COL_LOADS 10                    // tile loads a thread keeps in flight in the column kernels
 #define ASX_ROW_STEPS 5                     // max ceil(M2 / blockDim) in k_rows (bins a thread owns in the load / combine / store phases)
-#define ASX_PEARSON_BLOCKS 64               // partial-sum blocks per pair in a launch that fills the chip
-#define ASX_PEARSON_BLOCKS_MAX 512          // ... and in a launch of a few pairs (asx_pearson_blocks)
+#define ASX_PEARSON_BLOCKS_MAX 512          // upper limit of the partial-sum blocks per pair (asx_pearson_blocks: by the length alone)
+#define ASX_DC_STATS_DOUBLES (4 + 2 * 128)  // second look: {mean, sum, shift, -} + the per-block partials of k_dc_partial
 // Peak refinement (src/cross_correlation.c:52-67 is a float64 scan).  The transforms run in float32, so
 // every float32 r[k] is off by at most B = ASX_BOUND_C * eps32 * log2(F) * |source|_2 * |sample|_2
 // (a worst-case bound of the three transforms is ~3 eps log2 F; measured maximum 0.4 eps log2 F).
@@ -139,17 +139,19 @@ void asx_launch_refine_f32(const AsxDev &P, const float *src, const float *smp, 
 void asx_launch_refine_f64(const AsxDev &P, const double *src, const double *smp, const AsxPeakWs &W,
                            AsxSeg *seg, int npairs, hipStream_t s, int dot_blocks = ASX_DOT_BLOCKS);
 void asx_launch_pearson_f32(const float *src, const float *smp, size_t src_pitch, size_t smp_pitch,
-                            uint32_t basis_len, const AsxSeg *seg, double *psums, size_t psums_room, int64_t *lag,
+                            uint32_t basis_len, const AsxSeg *seg, double *psums, int64_t *lag,
                             double *coef, int32_t *ret, int npairs, hipStream_t s);
 void asx_launch_pearson_f64(const double *src, const double *smp, size_t src_pitch, size_t smp_pitch,
-                            uint32_t basis_len, const AsxSeg *seg, double *psums, size_t psums_room, int64_t *lag,
+                            uint32_t basis_len, const AsxSeg *seg, double *psums, int64_t *lag,
                             double *coef, int32_t *ret, int npairs, hipStream_t s);
 void asx_launch_results_to_ms(const int64_t *lag, const double *coef, const int32_t *ret, size_t batch,
                               double min_confidence, double sample_rate, int64_t *lag_ms, int32_t *accept,
                               hipStream_t s);
 void asx_launch_cvt_f64_f32(const double *in, float *out, size_t n, hipStream_t s);
+unsigned asx_pearson_blocks(uint32_t basis_len); // partial blocks per pair: psums holds 6 doubles per block and pair
 // second look, DC removal: stats[0] = mean of source[0..2N), stats[1] = sum of sample[0..N), stats[2] = scale * stats[0] * stats[1]
-// (scale = F: the device's r is F times the plain sum of products); out[i] = (float)(source[i] - stats[0])
+// (scale = F: the device's r is F times the plain sum of products); out[i] = (float)(source[i] - stats[0]); stats holds
+// ASX_DC_STATS_DOUBLES doubles
 void asx_launch_dc_remove_f32(const float *src, const float *smp, uint32_t N, double scale, double *stats, float *out, hipStream_t s);
 void asx_launch_dc_remove_f64(const double *src, const double *smp, uint32_t N, double scale, double *stats, float *out, hipStream_t s);
 void asx_launch_synth(uint64_t seed, uint64_t first_pair, size_t count, uint32_t N,

@@ -1094,9 +1094,8 @@ __global__ __launch_bounds__(ASX_THREADS) void k_pearson_partial(const TIn *__re
     __shared__ double red[6][ASX_THREADS / 64];
     const size_t pair = blockIdx.y;
     const AsxSeg s = seg[pair];
-    // gridDim.x partial blocks per pair (asx_pearson_blocks: 64 at most for a batch that fills the chip anyway, up to
-    // ASX_PEARSON_BLOCKS_MAX for a few pairs, whose pass is otherwise a chain of a few blocks' load latencies); the
-    // final kernel merges exactly gridDim.x entries
+    // gridDim.x partial blocks per pair (asx_pearson_blocks: by the basis length alone); the final kernel merges
+    // exactly gridDim.x entries
     const uint32_t chunk = (basis_len + gridDim.x - 1) / gridDim.x;
     const uint64_t lo = (uint64_t)blockIdx.x * chunk;
     uint64_t hi = lo + chunk;
@@ -1216,19 +1215,40 @@ __global__ __launch_bounds__(ASX_THREADS) void k_results_to_ms(const int64_t *__
 // transforms then run on a zero-mean source, whose norm no longer carries the offset, and the constant goes back in
 // when the keys are formed (peak_key_shifted).  The reference needs none of this: float64 (src/cross_correlation.c:34).
 // ---------------------------------------------------------------------------
+// grid (ASX_DC_BLOCKS): per-block sums of the source (2N) and the sample (N) in float64, 16-byte loads; the last
+// kernel (one wave) adds the partials in block order -- a fixed tree, the same for every call
+#define ASX_DC_BLOCKS 128
 template <typename TIn>
-__global__ __launch_bounds__(1024) void k_dc_stats(const TIn *__restrict__ src, const TIn *__restrict__ smp, uint32_t N,
-                                                    double scale, double *__restrict__ stats)
+__global__ __launch_bounds__(ASX_THREADS) void k_dc_partial(const TIn *__restrict__ src, const TIn *__restrict__ smp, uint32_t N,
+                                                             double *__restrict__ part)
 {
-    __shared__ double red[2][16];
+    __shared__ double red[2][ASX_THREADS / 64];
+    typedef TIn vec4u __attribute__((ext_vector_type(4), aligned(sizeof(TIn))));
     double a = 0.0, b = 0.0;
-    for (uint32_t i = threadIdx.x; i < 2u * N; i += 1024u) a += (double)src[i];
-    for (uint32_t i = threadIdx.x; i < N; i += 1024u) b += (double)smp[i];
+    const size_t stride = (size_t)gridDim.x * ASX_THREADS * 4, first = ((size_t)blockIdx.x * ASX_THREADS + threadIdx.x) * 4;
+    const size_t n2 = 2 * (size_t)N;
+    for (size_t i = first; i < n2; i += stride) {
+        if (i + 3 < n2) { const vec4u v = *reinterpret_cast<const vec4u *>(src + i); a += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w); }
+        else for (size_t k = i; k < n2; k++) a += (double)src[k];
+    }
+    for (size_t i = first; i < N; i += stride) {
+        if (i + 3 < N) { const vec4u v = *reinterpret_cast<const vec4u *>(smp + i); b += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w); }
+        else for (size_t k = i; k < N; k++) b += (double)smp[k];
+    }
     a = wave_sum(a); b = wave_sum(b);
     if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a; red[1][threadIdx.x >> 6] = b; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int w = 1; w < 16; w++) { a += red[0][w]; b += red[1][w]; }
+        for (int w = 1; w < ASX_THREADS / 64; w++) { a += red[0][w]; b += red[1][w]; }
+        part[2 * blockIdx.x] = a; part[2 * blockIdx.x + 1] = b;
+    }
+}
+__global__ __launch_bounds__(64) void k_dc_final(const double *__restrict__ part, uint32_t N, double scale, double *__restrict__ stats)
+{
+    double a = 0.0, b = 0.0;
+    for (int i = threadIdx.x; i < ASX_DC_BLOCKS; i += 64) { a += part[2 * i]; b += part[2 * i + 1]; }
+    a = wave_sum(a); b = wave_sum(b);
+    if (threadIdx.x == 0) {
         const double mean = a / (2.0 * (double)N);
         // the device's r is the unnormalised inverse transform, F times the plain sum of products (asx_api.hip,
         // bound_scale): the constant that goes back into the keys carries the same factor
@@ -1520,44 +1540,36 @@ void asx_launch_refine_f64(const AsxDev &P, const double *src, const double *smp
     hipLaunchKernelGGL(k_refine_pick, dim3(npairs), dim3(ASX_THREADS), 0, s, P.self_dev, W, seg);
 }
 
-// Partial blocks per pair: at least 16 sweeps of the block over its chunk (a block that only makes two
-// pays more for its reduction than for its loads: 1024 pairs of N = 144 000 ran at 3.0 TB/s with 64
-// blocks per pair against 5.7 TB/s at N = 1 440 000), at most ASX_PEARSON_BLOCKS.
-// ... unless the launch is so small (a single pair, the second look) that the chip would sit idle behind a few blocks'
-// chains of load latencies: then as many as give every thread one step, up to what the partial-sum buffer (`room`
-// entries for the launch) holds (single pair of N = 1 440 000: 21.5 -> 17.9 us)
-static unsigned asx_pearson_blocks(uint32_t basis_len, int npairs, size_t room)
+// Partial blocks per pair: a function of the segment's BASIS LENGTH ONLY -- one block per 16 sweeps of 256 threads x 4
+// elements (a block that only makes two sweeps pays more for its reduction than for its loads: 1024 pairs of
+// N = 144 000 ran at 3.0 TB/s with 64 blocks per pair against 5.7 TB/s at N = 1 440 000), at most
+// ASX_PEARSON_BLOCKS_MAX.  The chunks a pair is cut into, the pivots and the merge tree -- and so the last bits of its
+// coefficient -- are therefore the same whatever the batch it travels in, alone through cross_correlation(), in a group
+// of 124, re-run by the second look or on another shard (round 3 derived the count from the launch size).
+unsigned asx_pearson_blocks(uint32_t basis_len)
 {
     const uint32_t per_block = 16u * 4u * ASX_THREADS;
     uint32_t nb = (basis_len + per_block - 1) / per_block;
-    if (nb > ASX_PEARSON_BLOCKS) nb = ASX_PEARSON_BLOCKS;
-    if ((size_t)nb * (size_t)npairs < 2048u) {
-        const uint32_t one_step = (basis_len + 4u * ASX_THREADS - 1) / (4u * ASX_THREADS);
-        uint32_t want = (uint32_t)(2048u / (unsigned)npairs);
-        if (want > ASX_PEARSON_BLOCKS_MAX) want = ASX_PEARSON_BLOCKS_MAX;
-        if (want > one_step) want = one_step;
-        if (want > nb) nb = want;
-    }
-    if ((size_t)nb * (size_t)npairs > room) nb = (uint32_t)(room / (size_t)npairs);
+    if (nb > ASX_PEARSON_BLOCKS_MAX) nb = ASX_PEARSON_BLOCKS_MAX;
     if (nb < 1) nb = 1;
     return nb;
 }
 
 void asx_launch_pearson_f32(const float *src, const float *smp, size_t src_pitch, size_t smp_pitch,
-                            uint32_t basis_len, const AsxSeg *seg, double *psums, size_t psums_room, int64_t *lag,
+                            uint32_t basis_len, const AsxSeg *seg, double *psums, int64_t *lag,
                             double *coef, int32_t *ret, int npairs, hipStream_t s)
 {
-    const unsigned nb = asx_pearson_blocks(basis_len, npairs, psums_room);
+    const unsigned nb = asx_pearson_blocks(basis_len);
     hipLaunchKernelGGL(k_pearson_partial<float>, dim3(nb, npairs), dim3(ASX_THREADS), 0, s,
                        src, smp, src_pitch, smp_pitch, basis_len, seg, psums);
     hipLaunchKernelGGL(k_pearson_final, dim3(npairs), dim3(64), 0, s, seg, psums, nb, lag, coef, ret);
 }
 
 void asx_launch_pearson_f64(const double *src, const double *smp, size_t src_pitch, size_t smp_pitch,
-                            uint32_t basis_len, const AsxSeg *seg, double *psums, size_t psums_room, int64_t *lag,
+                            uint32_t basis_len, const AsxSeg *seg, double *psums, int64_t *lag,
                             double *coef, int32_t *ret, int npairs, hipStream_t s)
 {
-    const unsigned nb = asx_pearson_blocks(basis_len, npairs, psums_room);
+    const unsigned nb = asx_pearson_blocks(basis_len);
     hipLaunchKernelGGL(k_pearson_partial<double>, dim3(nb, npairs), dim3(ASX_THREADS), 0, s,
                        src, smp, src_pitch, smp_pitch, basis_len, seg, psums);
     hipLaunchKernelGGL(k_pearson_final, dim3(npairs), dim3(64), 0, s, seg, psums, nb, lag, coef, ret);
@@ -1583,12 +1595,14 @@ void asx_launch_cvt_f64_f32(const double *in, float *out, size_t n, hipStream_t 
 
 void asx_launch_dc_remove_f32(const float *src, const float *smp, uint32_t N, double scale, double *stats, float *out, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_dc_stats<float>, dim3(1), dim3(1024), 0, s, src, smp, N, scale, stats);
+    hipLaunchKernelGGL(k_dc_partial<float>, dim3(ASX_DC_BLOCKS), dim3(ASX_THREADS), 0, s, src, smp, N, stats + 4);
+    hipLaunchKernelGGL(k_dc_final, dim3(1), dim3(64), 0, s, stats + 4, N, scale, stats);
     hipLaunchKernelGGL(k_dc_apply<float>, dim3(512), dim3(ASX_THREADS), 0, s, src, N, stats, out);
 }
 void asx_launch_dc_remove_f64(const double *src, const double *smp, uint32_t N, double scale, double *stats, float *out, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_dc_stats<double>, dim3(1), dim3(1024), 0, s, src, smp, N, scale, stats);
+    hipLaunchKernelGGL(k_dc_partial<double>, dim3(ASX_DC_BLOCKS), dim3(ASX_THREADS), 0, s, src, smp, N, stats + 4);
+    hipLaunchKernelGGL(k_dc_final, dim3(1), dim3(64), 0, s, stats + 4, N, scale, stats);
     hipLaunchKernelGGL(k_dc_apply<double>, dim3(512), dim3(ASX_THREADS), 0, s, src, N, stats, out);
 }
 

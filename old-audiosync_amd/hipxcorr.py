@@ -24,7 +24,7 @@ ABI_SYMBOLS = [
     "asx_stream_append_f64", "asx_stream_lengths", "asx_stream_reset", "asx_stream_xcorr", "asx_synth_pairs_dev", "asx_plan_set_profiling",
     "asx_plan_last_timings_ms", "asx_device_malloc", "asx_device_free", "asx_memcpy_h2d",
     "asx_memcpy_d2h", "asx_stream_sync", "asx_plan_peak_overflows", "asx_plan_peak_repairs", "asx_plan_set_exact", "asx_plan_peak_capacity",
-    "asx_current_device", "asx_plan_timings_ms", "asx_xcorr_batch_multi",
+    "asx_current_device", "asx_plan_timings_ms", "asx_xcorr_batch_multi", "asx_plan_layout",
     "asx_host_malloc", "asx_host_free", "asx_shard_range", "asx_result_bytes", "asx_comm_create", "asx_comm_destroy", "asx_xcorr_batch_multi_dev",
 ]
 
@@ -81,6 +81,8 @@ def lib():
     L.asx_plan_threads.argtypes = [vp, c_intp, c_intp]
     L.asx_plan_split.restype = ctypes.c_int
     L.asx_plan_split.argtypes = [vp, c_intp, c_intp, c_intp]
+    L.asx_plan_layout.restype = ctypes.c_int
+    L.asx_plan_layout.argtypes = [vp]
     L.asx_xcorr_f64.restype = ctypes.c_int
     L.asx_xcorr_f64.argtypes = [vp, c_f64p, c_f64p, ctypes.POINTER(ctypes.c_long), c_f64p]
     L.asx_xcorr_batch_f32.restype = ctypes.c_int
@@ -427,6 +429,11 @@ class Plan:
         a, b, c = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
         lib().asx_plan_split(self._h, a, b, c)
         return a.value, b.value, c.value
+
+    @property
+    def layout(self):
+        """'real-column' (csrc/rlayout.hip) or 'packed' (csrc/xcorr_kernels.hip): which decomposition this plan runs"""
+        return "real-column" if lib().asx_plan_layout(self._h) == 1 else "packed"
 
     @property
     def threads(self):

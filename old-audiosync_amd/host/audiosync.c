@@ -207,18 +207,24 @@ static ssize_t read_chunk(int fd, void *dst, size_t want)
         }
         if (aborting()) return -2;
         if (pr == 0) continue;
+        if (pf.revents & POLLNVAL) { errno = EBADF; return -1; }
         const ssize_t r = read(fd, (char *) dst + got, want - got);
         if (r < 0) {
             if (errno == EINTR || errno == EAGAIN) continue;
             return -1;
         }
         if (r == 0) {
+            /* poll() returned at once and there is nothing to read: end of file (POLLIN / POLLHUP), or an error
+             * condition on the descriptor (POLLERR alone) -- which would otherwise bring poll() back immediately, round
+             * after round, at 100 % CPU */
             if (pf.revents & (POLLIN | POLLHUP)) break;
+            if (pf.revents & POLLERR) { errno = EIO; return -1; }
             continue;
         }
         got += (size_t) r;
     }
-    return (ssize_t) got;
+    /* whole frames only: a writer that dies inside a frame leaves a tail that is not a double */
+    return (ssize_t) (got - got % sizeof(double));
 }
 
 static void *producer(void *arg)
@@ -293,9 +299,10 @@ static void *producer(void *arg)
 int audiosync_run(const char *yt_title, long *lag)
 {
     DEBUG_ASSERT(yt_title); DEBUG_ASSERT(lag);
+    pthread_mutex_lock(&mutex);
     DEBUG_ASSERT(global_status == IDLE_ST);
-
     global_status = RUNNING_ST;
+    pthread_mutex_unlock(&mutex);
     int ret = -1;
     double confidence;
     pthread_t cap_th, down_th;
@@ -326,9 +333,11 @@ int audiosync_run(const char *yt_title, long *lag)
     /* the run keeps its own copies of the paths (the setters refuse while it is in progress, this is the belt) */
     if (cap_pa.in.path) cap_pa.in.path = strdup(cap_pa.in.path);
     if (down_pa.in.path) down_pa.in.path = strdup(down_pa.in.path);
+    /* (what the setters guard under the mutex is also read under it) */
+    const int lost_path = (feed_sample.path && !cap_pa.in.path) || (feed_source.path && !down_pa.in.path);
     pthread_mutex_unlock(&mutex);
     own_paths = 1;
-    if ((feed_sample.path && !cap_pa.in.path) || (feed_source.path && !down_pa.in.path)) {
+    if (lost_path) {
         perror("audiosync: strdup for the feed paths failed");
         goto finish;
     }
@@ -393,7 +402,9 @@ finish:
     asx_host_free(sample);
     asx_host_free(source);
     if (own_paths) { free(cap_pa.in.path); free(down_pa.in.path); }
+    pthread_mutex_lock(&mutex);
     global_status = IDLE_ST;
+    pthread_mutex_unlock(&mutex);
     LOG("finished run");
     return ret;
 }

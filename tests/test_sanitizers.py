@@ -50,3 +50,13 @@ def test_producers_and_state_machine(san, binary, tmp_path):
     """pause / resume / abort of a slow memory feed, abort of a run whose FIFO writer never starts, feed setters refused
     during a run (host/audiosync.c)"""
     assert "0 failures" in run([os.path.join(san, binary), str(tmp_path)])
+
+
+@pytest.mark.parametrize("binary", ["shard_tsan", "shard_asan"])
+def test_sharded_batch_driver_without_hardware(san, binary):
+    """csrc/shard_driver.cpp -- the thread / partition / record-layout logic of asx_xcorr_batch_multi_dev (SURVEY.md 8e),
+    which has never met a second GPU -- on host-memory stand-ins for the device operations: 1, 2, 3 and 8 shards, uneven
+    counts, a failing shard (error returned, every thread joined, every stream drained before the call returns), a failing
+    record allocation (no stale width), width changes (VERDICT r3 #6, ADVICE r3)"""
+    out = run([os.path.join(san, binary)])
+    assert ", 0 failures" in out and not out.startswith("0 cases")

@@ -118,6 +118,7 @@ def test_c_abi_partition_matches_the_python_one():
                 assert start == nxt
                 nxt += count
             assert nxt == total
-    assert mod.result_bytes(5) == 5 * 20
+    assert mod.result_bytes(5) == 104 and mod.result_bytes(6) == 120      # 20 bytes per pair, rounded up to 8
+    assert all(mod.result_bytes(w) == sharding.result_bytes(w) for w in range(1, 40))
     with pytest.raises(mod.AsxError):
         mod.shard_range(10, 0, 0)

@@ -16,6 +16,7 @@ done
 /opt/rocm/bin/hipcc $F -mllvm -amdgpu-sched-strategy=iterative-ilp $flags -c -o $D/rlayout.o $P/csrc/rlayout.hip &
 /opt/rocm/bin/hipcc $F $flags -c -o $D/api.o $P/csrc/asx_api.hip &
 /opt/rocm/bin/hipcc $F $flags -c -o $D/plan.o $P/csrc/plan_math.cpp &
+/opt/rocm/bin/hipcc $F $flags -c -o $D/shard.o $P/csrc/shard_driver.cpp &
 wait
-/opt/rocm/bin/hipcc -fPIC --offload-arch=gfx950 -shared -o $R/ab/$name.so $D/api.o $D/plan.o $D/rlayout.o $objs -ldl
+/opt/rocm/bin/hipcc -fPIC --offload-arch=gfx950 -shared -o $R/ab/$name.so $D/api.o $D/plan.o $D/shard.o $D/rlayout.o $objs -ldl
 echo "ab/$name.so"
