@@ -43,6 +43,10 @@ BYTES_PER_FRAME = 52             # A(N) = 52*N bytes per cross-c
 ALGO_SHARE = {"fwd_cols": 28, "rows": 16, "inv_cols": 0, "pearson": 8}   # DESIGN.md "Algorithmic bytes"
 FAMILIES = ("fwd_cols", "rows", "inv_cols", "finalize", "pearson", "total")
 CONFIG4_BATCH, CONFIG4_N = 8192, 480000
+# BASELINE.json configs[3] is a STRONG-scaling curve (fixed batch): the speed-up at N GPUs is this object's `value` in the
+# N-GPU line over its `value` in the 1-GPU line of the same sweep; the top-level `value` is the weak-scaling headline.
+CONFIG4_SPEEDUP_BASIS = ("config4.value(n_gpus = N) / config4.value(n_gpus = 1) of the same sweep: a fixed batch of %d pairs of "
+                         "N = %d block-partitioned over the ranks, result all-gather inside the timed region" % (CONFIG4_BATCH, CONFIG4_N))
 SEED = 20260101
 
 
@@ -319,8 +323,12 @@ def dry_run(args):
     t = torch.tensor([1.0 if ok else 0.0])
     dist.all_reduce(t, op=dist.ReduceOp.MIN)
     if rank == 0:
+        width4 = (CONFIG4_BATCH + world - 1) // world
         print(json.dumps({"dry_run": True, "n_gpus": world, "world_size_seen": dist.get_world_size(), "backend": "gloo",
-                          "results_ok": bool(t.item() == 1.0), "shards_rank0": report}), flush=True)
+                          "results_ok": bool(t.item() == 1.0), "shards_rank0": report, "scaling": "weak",
+                          "config4": {"scaling": "strong", "speedup_basis": CONFIG4_SPEEDUP_BASIS, "n_gpus": world,
+                                      "pairs_total": CONFIG4_BATCH, "pairs_per_gpu": report["config4"]["shard"][1],
+                                      "record_bytes_per_rank": sharding.result_bytes(width4)}}), flush=True)
     dist.destroy_process_group()
     return 0 if t.item() == 1.0 else 1
 
@@ -511,8 +519,9 @@ def run_rank(args, cpu=None):
             ok4 = w4.verify()
             cfg4 = {"metric": "cross-correlations/sec (fixed batch %d x N=%d, strong scaling)" % (CONFIG4_BATCH, CONFIG4_N),
                     "value": CONFIG4_BATCH * args.steps4 / dt4, "unit": "cross-correlations/s", "scaling": "strong",
+                    "speedup_basis": CONFIG4_SPEEDUP_BASIS,
                     "n_gpus": world, "steps": args.steps4, "ms_per_step": dt4 / args.steps4 * 1e3,
-                    "pairs_per_gpu": w4.count, "results_ok": ok4,
+                    "pairs_total": CONFIG4_BATCH, "pairs_per_gpu": w4.count, "results_ok": ok4,
                     "path_frac_of_hbm_roofline": BYTES_PER_FRAME * CONFIG4_N * CONFIG4_BATCH * args.steps4 / dt4 / world / 1e9 / HBM_PEAK_GBS,
                     "workload": "BASELINE configs[3]: %d pairs, N=%d, SNR -6 dB, block-partitioned over %d rank(s), inputs "
                                 "generated on the device per shard (%.1f GB per rank), result all-gather timed" %

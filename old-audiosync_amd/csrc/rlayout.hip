@@ -681,7 +681,15 @@ bool asx_launch_rows_r(const AsxDev &P, const float2 *cx, const float2 *cy, floa
     }
     ASX_ROWSR_CASE(128, false, 1200, 12, 10, 10)
     ASX_ROWSR_CASE(128, true, 1200, 12, 10, 10)
-    ASX_ROWSR_CASE(128, false, 480, 10, 8, 6)
+    // 480-point rows: ONE wave per block -- a block is 11.5 KB of traffic and a chain of five short phases, so what counts is
+    // how many are in flight: sixteen single-wave blocks per CU against eight of two waves (rows 0.93 -> 0.83 ms per 1024
+    // pairs of N = 144 000, same box)
+#ifndef ASX_ROWSR_480
+#define ASX_ROWSR_480 64, false, 480, 10, 8, 6
+#endif
+#define ASX_ROWSR_CASE_X(...) ASX_ROWSR_CASE(__VA_ARGS__)
+    ASX_ROWSR_CASE_X(ASX_ROWSR_480)
+#undef ASX_ROWSR_CASE_X
 #undef ASX_ROWSR_CASE
     return false;
 }
@@ -689,14 +697,25 @@ bool asx_launch_rows_r(const AsxDev &P, const float2 *cx, const float2 *cy, floa
 // Column schedules of the production sample lengths (plan_math.cpp's tuned table):  X(M1, tile width in real columns,
 // block size, radices...).  (1200- and 800-row tiles hold only eight real columns: 32-byte input pieces, measured 25 % slower
 // in k_fwd_cols_r, and a fed first stage of radix 10 needs 20 rows in flight per thread: the two longest lengths use 600 / 400
-// rows with 2400-point rows instead.)
+// rows with 2400-point rows instead.)  Block sizes are measured (tools/dbg/nt_sweep.sh, round 4): 400-row tiles 512
+// threads (320, the packed kernels' choice: 12 % slower at N = 480 000), 300-row tiles 256 (320 / 384 / 512: 20-35 % slower).
 #define ASX_RCOLS(X) \
-    X(600, 16, 512, 10, 10, 6) X(400, 16, 320, 10, 8, 5) X(300, 16, 256, 10, 6, 5)
+    X(600, 16, 512, 10, 10, 6) X(400, 16, 512, 10, 8, 5) X(300, 16, 256, 10, 6, 5) ASX_RCOLS_EXTRA(X)
+#ifndef ASX_RCOLS_EXTRA
+#define ASX_RCOLS_EXTRA(X)
+#endif
 
 static void allow_big_lds_r(const void *fn, size_t bytes)
 {
     if (bytes > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
+
+static int rcol_nt_override()
+{
+    static const int v = getenv("ASX_RCOL_NT") ? atoi(getenv("ASX_RCOL_NT")) : 0; // diagnostic: block size of the column kernels
+    return v;
+}
+#define ASX_RCOL_NT_OK(nt) (rcol_nt_override() == 0 || rcol_nt_override() == (nt))
 
 bool asx_launch_fwd_cols_r(const AsxDev &P, const float *src, const float *smp, float2 *cx, float2 *cy, const AsxPeakWs &W,
                            int npairs, hipStream_t s)
@@ -705,7 +724,7 @@ bool asx_launch_fwd_cols_r(const AsxDev &P, const float *src, const float *smp, 
     const size_t pitch = ((size_t)P.M1 + 1) * (size_t)P.M2, lds = (size_t)P.M1 * P.T * sizeof(float2);
     const dim3 grid(rcol_grid_x(P.ntiles, P.logT), 2, npairs);
 #define ASX_TRY(m1, t, nt, ...)                                                                                             \
-    if (P.T == (t) && schedule_is_r(P.st1, m1, { __VA_ARGS__ })) {                                                          \
+    if (P.T == (t) && ASX_RCOL_NT_OK(nt) && schedule_is_r(P.st1, m1, { __VA_ARGS__ })) {                                    \
         allow_big_lds_r((const void *)k_fwd_cols_r<Sched<m1, __VA_ARGS__>, t, nt>, lds);                                    \
         hipLaunchKernelGGL((k_fwd_cols_r<Sched<m1, __VA_ARGS__>, t, nt>), grid, dim3(nt), lds, s, P.self_dev, src, smp, cx, cy, \
                            W.nrm_part, pitch);                                                                              \
@@ -722,7 +741,7 @@ bool asx_launch_inv_cols_r(const AsxDev &P, const float2 *q, const AsxPeakWs &W,
     const size_t pitch = ((size_t)P.M1 + 1) * (size_t)P.M2, lds = (size_t)P.M1 * P.T * sizeof(float2);
     const dim3 grid(rcol_grid_x(P.ntiles, P.logT), npairs);
 #define ASX_TRY(m1, t, nt, ...)                                                                                             \
-    if (P.T == (t) && schedule_is_r(P.st1, m1, { __VA_ARGS__ })) {                                                          \
+    if (P.T == (t) && ASX_RCOL_NT_OK(nt) && schedule_is_r(P.st1, m1, { __VA_ARGS__ })) {                                    \
         allow_big_lds_r((const void *)k_inv_cols_r<Sched<m1, __VA_ARGS__>, t, nt>, lds);                                    \
         hipLaunchKernelGGL((k_inv_cols_r<Sched<m1, __VA_ARGS__>, t, nt>), grid, dim3(nt), lds, s, P.self_dev, q, pitch, W, r_out); \
         return true;                                                                                                        \

@@ -40,3 +40,18 @@ def test_a_failing_rank_fails_the_launcher():
     # a rank that cannot form the group (bad backend request) must surface as a non-zero exit code
     p, line = run_bench("--gpus", "2", "--dry-run", env_extra={"ASX_BENCH_DRYRUN_FAIL": "1"})
     assert p.returncode != 0
+
+
+def test_gpus_8_the_node_size_of_baseline_config_4():
+    """BASELINE.json configs[3]: 8192 pairs over the 8 GPUs of a node.  No 8-GPU node was available to rounds 1-4; this is
+    the rank / shard / gather path at that world size on CPU (gloo), and the shape of the strong-scaling record a future
+    SCALE run needs: config4.value per n_gpus with its speed-up basis stated (VERDICT r3 #6)."""
+    p, line = run_bench("--gpus", "8", "--dry-run")
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert line["n_gpus"] == 8 and line["world_size_seen"] == 8 and line["results_ok"] is True
+    assert line["shards_rank0"]["config4"] == {"total": 8192, "shard": [0, 1024]}
+    assert line["shards_rank0"]["headline"] == {"total": 48, "shard": [0, 6]}
+    c4 = line["config4"]
+    assert c4["scaling"] == "strong" and c4["n_gpus"] == 8 and c4["pairs_per_gpu"] == 1024 and c4["pairs_total"] == 8192
+    assert "n_gpus = 1" in c4["speedup_basis"] and c4["record_bytes_per_rank"] == 1024 * 20
+    assert line["scaling"] == "weak"
