@@ -469,7 +469,7 @@ __global__ __launch_bounds__(NT, 4) void k_inv_cols_r(const AsxDev *__restrict__
     __shared__ float s_b2;
     const size_t pair = blockIdx.y;
     const int tile = rcol_tile_of_block(blockIdx.x, logT);
-    if (tile >= P.ntiles) return;
+    if (tile * T >= P.M2) return; // grid.x is rounded up; the tile width is this kernel's own (it reads only)
     // a digitally silent track: r is exactly zero everywhere, the running maximum stays zero = index 0 (see k_inv_cols)
     if (W.bound2[pair] == 0.f && r_out == nullptr) return;
     const double shift = W.shift ? W.shift[pair] : 0.0; // non-zero only in the second look (asx_api.hip)
@@ -735,18 +735,24 @@ bool asx_launch_fwd_cols_r(const AsxDev &P, const float *src, const float *smp, 
     return false;
 }
 
+// The inverse column kernel only reads: its tile width is its own (ASX_RINV: X(M1, width, block size, radices...)), not tied to
+// the width k_fwd_cols_r writes C with.
+#ifndef ASX_RINV
+#define ASX_RINV(X) ASX_RCOLS(X)
+#endif
 bool asx_launch_inv_cols_r(const AsxDev &P, const float2 *q, const AsxPeakWs &W, float *r_out, int npairs, hipStream_t s)
 {
     if (!P.col_pairs) return false;
-    const size_t pitch = ((size_t)P.M1 + 1) * (size_t)P.M2, lds = (size_t)P.M1 * P.T * sizeof(float2);
-    const dim3 grid(rcol_grid_x(P.ntiles, P.logT), npairs);
+    const size_t pitch = ((size_t)P.M1 + 1) * (size_t)P.M2;
 #define ASX_TRY(m1, t, nt, ...)                                                                                             \
-    if (P.T == (t) && ASX_RCOL_NT_OK(nt) && schedule_is_r(P.st1, m1, { __VA_ARGS__ })) {                                    \
+    if (P.M2 % (t) == 0 && ASX_RCOL_NT_OK(nt) && schedule_is_r(P.st1, m1, { __VA_ARGS__ })) {                               \
+        const size_t lds = (size_t)(m1) * (t) * sizeof(float2);                                                             \
+        const dim3 grid(rcol_grid_x(P.M2 / (t), asx_ilog2(t)), npairs);                                                     \
         allow_big_lds_r((const void *)k_inv_cols_r<Sched<m1, __VA_ARGS__>, t, nt>, lds);                                    \
         hipLaunchKernelGGL((k_inv_cols_r<Sched<m1, __VA_ARGS__>, t, nt>), grid, dim3(nt), lds, s, P.self_dev, q, pitch, W, r_out); \
         return true;                                                                                                        \
     }
-    ASX_RCOLS(ASX_TRY)
+    ASX_RINV(ASX_TRY)
 #undef ASX_TRY
     return false;
 }
