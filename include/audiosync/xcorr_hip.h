@@ -116,6 +116,13 @@ size_t asx_plan_workspace_bytes(const asx_plan *plan);
  * NaN coefficient: outputs written). */
 int asx_xcorr_f64(asx_plan *plan, const double *source, const double *sample, long *lag,
                   double *coefficient);
+/* When EVERY double of both buffers is exactly a float32 -- true of whatever ffmpeg decodes from 16-bit or float audio,
+ * although the reference asks it for f64le (src/capture/linux_capture.c:370) -- asx_xcorr_f64 moves 4 bytes per frame across PCIe instead of 8: the check and the conversion run on a small host thread pool
+ * ($ASX_HOST_THREADS, default 12 or the cgroup's CPU quota) into page-locked staging, overlapped with the uploads, and the float64 passes read the
+ * float32 copy widened on the device: the same values, the same operations, the same bits.  Anything else (a NaN, a value
+ * with more than 24 significant bits) takes the 8-byte route.  $ASX_NARROW=0 switches the check off.
+ * asx_plan_narrowed_calls(): how many asx_xcorr_f64 calls on this plan went the 4-byte way. */
+int asx_plan_narrowed_calls(asx_plan *plan, uint64_t *count);
 
 /* `batch` pairs, host float32 buffers laid out pair after pair:
  * source[batch][2N], sample[batch][N].  lag/coef/ret: `batch` entries each. */

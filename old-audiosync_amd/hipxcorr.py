@@ -24,7 +24,7 @@ ABI_SYMBOLS = [
     "asx_stream_append_f64", "asx_stream_lengths", "asx_stream_reset", "asx_stream_xcorr", "asx_synth_pairs_dev", "asx_plan_set_profiling",
     "asx_plan_last_timings_ms", "asx_device_malloc", "asx_device_free", "asx_memcpy_h2d",
     "asx_memcpy_d2h", "asx_stream_sync", "asx_plan_peak_overflows", "asx_plan_peak_repairs", "asx_plan_set_exact", "asx_plan_peak_capacity",
-    "asx_current_device", "asx_plan_timings_ms", "asx_xcorr_batch_multi", "asx_plan_layout",
+    "asx_current_device", "asx_plan_timings_ms", "asx_xcorr_batch_multi", "asx_plan_layout", "asx_plan_narrowed_calls",
     "asx_host_malloc", "asx_host_free", "asx_shard_range", "asx_result_bytes", "asx_comm_create", "asx_comm_destroy", "asx_xcorr_batch_multi_dev",
 ]
 
@@ -73,6 +73,8 @@ def lib():
     L.asx_plan_set_exact.argtypes = [vp, ctypes.c_int]
     L.asx_plan_peak_repairs.restype = ctypes.c_int
     L.asx_plan_peak_repairs.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
+    L.asx_plan_narrowed_calls.restype = ctypes.c_int
+    L.asx_plan_narrowed_calls.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
     for name in ("asx_plan_sample_len", "asx_plan_fft_len", "asx_plan_group", "asx_plan_workspace_bytes",
                  "asx_plan_peak_capacity"):
         getattr(L, name).restype = ctypes.c_size_t
@@ -412,6 +414,13 @@ class Plan:
         once per call for its kernels); off: that entry point stays asynchronous and marks such pairs with ret = 1"""
         if lib().asx_plan_set_exact(self._h, 1 if on else 0) != 0:
             raise AsxError(_err())
+
+    def narrowed_calls(self):
+        """xcorr_f64 calls whose frames were all exactly float32 and crossed PCIe as 4 bytes each"""
+        c = ctypes.c_uint64(0)
+        if lib().asx_plan_narrowed_calls(self._h, ctypes.byref(c)) != 0:
+            raise AsxError(_err())
+        return c.value
 
     def peak_repairs(self):
         """overflowing pairs that were looked at again with lists for all 2N lags"""

@@ -365,3 +365,40 @@ def test_moderate_offsets_where_the_shift_is_comparable_to_r(mod):
         assert (int(ret[0]), int(lag[0])) == (o_ret, o_lag), (off, int(lag[0]), o_lag, margin)
         assert abs(float(coef[0]) - o_coef) < COEF_TOL
     assert repairs >= 2          # the larger offsets do take the second look
+
+
+def test_float32_exact_doubles_cross_pcie_as_float32_and_give_the_same_bits(mod):
+    """cross_correlation(double*) on frames that are exactly float32 (what ffmpeg decodes from 16-bit / float
+    audio, src/capture/linux_capture.c:370) uploads 4 bytes per frame and runs the float64 passes on the widened copy: the
+    coefficient is bit-identical to the batched float32 entry point's (the same values through the same operations) and
+    within 1e-5 of the oracle; doubles that float32 cannot hold, and NaNs, keep the 8-byte route."""
+    n = 144000
+    src32, smp32, true_lag = oracle.synth_pair(55, 1, n, 1)
+    s64, t64 = src32.astype(np.float64), smp32.astype(np.float64)
+    with mod.Plan(n, 1, 0) as plan:
+        ret, lag, coef = plan.xcorr_f64(s64, t64)
+        assert plan.narrowed_calls() == 1
+        lag_b, coef_b, ret_b = plan.xcorr_batch_f32(src32[None], smp32[None])
+        assert (ret, lag) == (int(ret_b[0]), int(lag_b[0])) == (0, true_lag) and coef == float(coef_b[0])
+        o_ret, o_lag, o_coef = oracle.cross_correlation(s64, t64)
+        assert (ret, lag) == (o_ret, o_lag) and abs(coef - o_coef) < 1e-5
+        # low bits float32 cannot hold: the 8-byte route, the doubles themselves in the Pearson pass
+        s_lo, t_lo = s64 * (1.0 + 1e-9), t64 * (1.0 - 3e-10)
+        ret2, lag2, coef2 = plan.xcorr_f64(s_lo, t_lo)
+        assert plan.narrowed_calls() == 1
+        o_ret, o_lag, o_coef = oracle.cross_correlation(s_lo, t_lo)
+        assert (ret2, lag2) == (o_ret, o_lag) and abs(coef2 - o_coef) < 1e-5
+        # one inexact frame at the very end of the sample: the source has already gone up narrowed, the call must still be right
+        t_one = t64.copy(); t_one[-1] = 0.1
+        ret3, lag3, coef3 = plan.xcorr_f64(s64, t_one)
+        assert plan.narrowed_calls() == 1
+        o_ret, o_lag, o_coef = oracle.cross_correlation(s64, t_one)
+        assert (ret3, lag3) == (o_ret, o_lag) and abs(coef3 - o_coef) < 1e-5
+        # a NaN is never "exactly a float32": the reference's NaN behaviour comes from the 8-byte route
+        s_nan = s64.copy(); s_nan[7] = np.nan
+        ret4, lag4, coef4 = plan.xcorr_f64(s_nan, t64)
+        assert plan.narrowed_calls() == 1
+        o_ret, o_lag, o_coef = oracle.cross_correlation(s_nan, t64)
+        assert (ret4, lag4) == (o_ret, o_lag)
+        # and the exact frames again: 4 bytes
+        assert plan.xcorr_f64(s64, t64) == (ret, lag, coef) and plan.narrowed_calls() == 2

@@ -60,3 +60,11 @@ def test_sharded_batch_driver_without_hardware(san, binary):
     record allocation (no stale width), width changes (VERDICT r3 #6, ADVICE r3)"""
     out = run([os.path.join(san, binary)])
     assert ", 0 failures" in out and not out.startswith("0 cases")
+
+
+@pytest.mark.parametrize("binary", ["narrow_tsan", "narrow_asan"])
+def test_float32_exactness_check_of_the_double_abi(san, binary):
+    """csrc/host_narrow.cpp -- the worker pool that converts the reference's double buffers to float32 while checking that
+    nothing is lost (then 4 bytes per frame cross PCIe instead of 8) -- exact and inexact buffers, NaNs, ragged sizes,
+    four concurrent callers"""
+    assert ", 0 failures" in run([os.path.join(san, binary)])

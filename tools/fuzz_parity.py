@@ -19,7 +19,7 @@ L.cross_correlation.restype = ctypes.c_int
 L.cross_correlation.argtypes = [dp, dp, ctypes.c_size_t, ctypes.POINTER(ctypes.c_long), dp]
 PROD = [144000, 288000, 480000] if os.environ.get("FUZZ_BIG") == "1" else [144000, 288000]
 if os.environ.get("FUZZ_HUGE") == "1": PROD = [720000, 960000, 1440000]
-t0 = time.time(); trials = checked = 0
+t0 = time.time(); trials = checked = 0; layouts = {}
 while time.time() - t0 < budget:
     r = rng.uniform()
     if os.environ.get("FUZZ_BIG") == "1": r *= 0.5   # FUZZ_BIG=1: only the production and the large lengths
@@ -52,6 +52,18 @@ while time.time() - t0 < budget:
     s32, t32 = src.astype(np.float32), smp.astype(np.float32)
     with asx.Plan(n, batch, 0) as plan:
         lag, coef, ret = plan.xcorr_batch_f32(s32, t32)
+        # the device-resident entry point (what bench.py times): the same answers, bit for bit -- it takes the second look
+        # at overflowed pairs itself since round 4
+        d_s = torch.from_numpy(s32).cuda(); d_t = torch.from_numpy(t32).cuda()
+        d_lag = torch.full((batch,), -99, dtype=torch.int64, device="cuda"); d_coef = torch.zeros(batch, dtype=torch.float64, device="cuda")
+        d_ret = torch.full((batch,), 7, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        plan.xcorr_batch_dev(d_s.data_ptr(), d_t.data_ptr(), batch, d_lag.data_ptr(), d_coef.data_ptr(), d_ret.data_ptr())
+        plan.sync()
+        assert np.array_equal(d_lag.cpu().numpy(), np.asarray(lag)) and np.array_equal(d_ret.cpu().numpy(), np.asarray(ret)), ("dev", trials, n, kind)
+        dc = d_coef.cpu().numpy()
+        assert all((a == b) or (a != a and b != b) for a, b in zip(dc, np.asarray(coef))), ("dev coef", trials, n, kind)
+        layouts[plan.layout] = layouts.get(plan.layout, 0) + 1
     for b in range(batch):
         o_ret, o_lag, o_coef, o_r, margin = oracle.cross_correlation(s32[b], t32[b], want_results=True)
         if margin < 1.0 + (1e-11 if kind == 6 else 1e-9) and not silent:
@@ -72,4 +84,4 @@ while time.time() - t0 < budget:
                 assert abs(cf.value - o_coef) < 1e-5, ("f64 coef", trials, n, cf.value, o_coef)
             checked += 1
     trials += 1
-print("fuzz ok: %d problems, %d pairs checked against the oracle in %.0f s" % (trials, checked, time.time() - t0))
+print("fuzz ok: %d problems, %d pairs checked against the oracle in %.0f s; plans by decomposition: %s" % (trials, checked, time.time() - t0, layouts))

@@ -17,6 +17,7 @@ done
 /opt/rocm/bin/hipcc $F $flags -c -o $D/api.o $P/csrc/asx_api.hip &
 /opt/rocm/bin/hipcc $F $flags -c -o $D/plan.o $P/csrc/plan_math.cpp &
 /opt/rocm/bin/hipcc $F $flags -c -o $D/shard.o $P/csrc/shard_driver.cpp &
+/opt/rocm/bin/hipcc $F $flags -c -o $D/narrow.o $P/csrc/host_narrow.cpp &
 wait
-/opt/rocm/bin/hipcc -fPIC --offload-arch=gfx950 -shared -o $R/ab/$name.so $D/api.o $D/plan.o $D/shard.o $D/rlayout.o $objs -ldl
+/opt/rocm/bin/hipcc -fPIC --offload-arch=gfx950 -shared -o $R/ab/$name.so $D/api.o $D/plan.o $D/shard.o $D/narrow.o $D/rlayout.o $objs -ldl -lpthread
 echo "ab/$name.so"
