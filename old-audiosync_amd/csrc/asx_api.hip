@@ -247,6 +247,7 @@ static int plan_init(asx_plan *p, size_t N, size_t max_batch, const char *split)
         p->lanes[l].pk.over_n = p->over_n;
         p->lanes[l].pk.over_cap = (uint32_t)p->over_cap;
     }
+    if (const char *e = getenv("ASX_EXACT")) p->exact = atoi(e) != 0; // initial value of asx_plan_set_exact (A/B of its cost)
     HIP_TRY(hipEventCreateWithFlags(&p->fork, hipEventDisableTiming));
     d.stamps = nullptr;
     d.stamp_kernel = 0;
