@@ -253,7 +253,7 @@ static int plan_init(asx_plan *p, size_t N, size_t max_batch, const char *split)
     d.stamp_kernel = 0;
     if (const char *e = getenv("ASX_STAMPS")) {
         unsigned long long *st = nullptr;
-        p->stamp_blocks = g * (size_t)std::max(h.M1 / 2 + 1, 2 * h.ntiles);
+        p->stamp_blocks = g * (size_t)std::max(h.M1 + 1, 2 * h.ntiles);
         if (dev_alloc(p, &st, p->stamp_blocks * 8)) return -1;
         HIP_TRY(hipMemset(st, 0, p->stamp_blocks * 8 * sizeof(unsigned long long)));
         d.stamps = st;

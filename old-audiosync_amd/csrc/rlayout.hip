@@ -37,6 +37,47 @@
 
 extern __shared__ __attribute__((aligned(16))) float2 asx_lds_r[];
 
+// Diagnostic phase clocks (never in a shipped build; -DASX_STAMPS, tools/dbg/stamps_r.py): lane 0 of a block records the
+// clock at phase boundaries into a buffer nothing else reads (kernel 0 = rows, 1 = forward columns, 2 = inverse columns).
+#ifdef ASX_STAMPS
+#define RSTAMP(kernel, block, slot)                                                                  \
+    do {                                                                                             \
+        if (P.stamps && P.stamp_kernel == (kernel) && threadIdx.x == 0)                              \
+            P.stamps[(size_t)(block) * 8 + (slot)] = clock64();                                      \
+    } while (0)
+#else
+#define RSTAMP(kernel, block, slot) do {} while (0)
+#endif
+
+// What these kernels need from the plan, BY VALUE in the kernel arguments.  Read through the plan pointer (as the
+// packed-sample kernels do) a block starts with a chain of dependent latencies -- plan struct (scalar loads) -> table
+// pointers -> twiddle lookups, and in the inverse column kernel a bound load + branch before the tile loads were even
+// issued: 4-5 k cycles, a fifth of a block's life (tools/dbg/stamps_r.py, round 4).  No arrays in here: nothing the
+// compiler would index dynamically and send to scratch.
+struct RArgs {
+    const float2 *tw1, *tw2, *tw_lo, *tw_hi;
+    uint32_t N, nout;
+    int M2, ntiles;
+    float bound_scale;
+    unsigned long long *stamps;
+    int stamp_kernel;
+};
+static RArgs rargs_of(const AsxDev &P)
+{
+    RArgs a;
+    a.tw1 = P.tw1; a.tw2 = P.tw2; a.tw_lo = P.tw_lo; a.tw_hi = P.tw_hi;
+    a.N = P.N; a.nout = P.nout; a.M2 = P.M2; a.ntiles = P.ntiles; a.bound_scale = P.bound_scale;
+    a.stamps = P.stamps; a.stamp_kernel = P.stamp_kernel;
+    return a;
+}
+// w_F^p from the two-level table (xcorr_dev.h's tw_F on the argument block)
+__device__ __forceinline__ float2 tw_F(const RArgs &P, uint32_t p)
+{
+    const float2 lo = P.tw_lo[p & (ASX_TW_LO - 1u)];
+    const float2 hi = P.tw_hi[p >> ASX_TW_LOG];
+    return cmul(lo, hi);
+}
+
 // single-member values live in the first 8 bytes of a 16-byte slot: the wave-local stages rewrite exactly the
 // slots they read, so no other wave's data is ever touched
 __device__ __forceinline__ Cx1 lds_get1(const float4 *p)
@@ -76,7 +117,7 @@ __device__ __forceinline__ void wave_lds_sync()
 //                pieces, whole 128-byte lines of C and Q) instead of 1200 / 800 rows of eight.
 // ---------------------------------------------------------------------------
 template <class S, int NT, bool TWO>
-__global__ __launch_bounds__(TWO ? 2 * NT : NT, ASX_ROWSR_WAVES) void k_rows_r(const AsxDev *__restrict__ Pp, const float2 *__restrict__ cx,
+__global__ __launch_bounds__(TWO ? 2 * NT : NT, ASX_ROWSR_WAVES) void k_rows_r(const RArgs P, const float2 *__restrict__ cx,
                                                                                 const float2 *__restrict__ cy, float2 *__restrict__ qo,
                                                                                 int nrows, size_t pair_pitch, AsxPeakWs W)
 {
@@ -95,8 +136,9 @@ __global__ __launch_bounds__(TWO ? 2 * NT : NT, ASX_ROWSR_WAVES) void k_rows_r(c
     constexpr int LPU = R1 > R2 ? R1 : R2, UPW = 64 / LPU, NW = NT / 64;
     static_assert(NT % 64 == 0 && UPW >= 1, "whole waves");
 
-    const AsxDev &PD = *Pp;
-    const AsxKP P = asx_kp(PD);
+#ifdef ASX_STAMPS
+    const long long t_entry = clock64(), w_entry = wall_clock64();
+#endif
     const int task = blockIdx.x, tid = threadIdx.x;
     const int half = TWO ? tid / NT : 0, lt = tid - half * NT; // which sub-row, thread index inside its half
     float4 *A4 = reinterpret_cast<float4 *>(asx_lds_r) + half * NS;
@@ -114,7 +156,7 @@ __global__ __launch_bounds__(TWO ? 2 * NT : NT, ASX_ROWSR_WAVES) void k_rows_r(c
         for (int t = tid; t < P.ntiles; t += 64) { sx += np[t]; sy += np[P.ntiles + t]; }
         sx = wave_sum_f32(sx); sy = wave_sum_f32(sy);
         if (tid == 0) {
-            W.bound2[pair] = PD.bound_scale * sqrtf(sx) * sqrtf(sy);
+            W.bound2[pair] = P.bound_scale * sqrtf(sx) * sqrtf(sy);
             W.pairmax[pair] = 0;
             W.cand_n[pair] = 0;
         }
@@ -152,6 +194,10 @@ __global__ __launch_bounds__(TWO ? 2 * NT : NT, ASX_ROWSR_WAVES) void k_rows_r(c
     const int ul = lane / LPU, jl = lane - ul * LPU;
     const int j1c = jl < R2 ? jl : 0;
     const float2 s1w1 = P.tw2[TWS * K1.twmul * j1c], s1w4 = P.tw2[TWS * (R1 > 4 ? 4 : 1) * K1.twmul * j1c];
+    RSTAMP(0, task, 0);
+#ifdef ASX_STAMPS
+    if (P.stamps && P.stamp_kernel == 0 && threadIdx.x == 0) { P.stamps[(size_t)task * 8 + 6] = t_entry; P.stamps[(size_t)task * 8 + 7] = w_entry; }
+#endif
     __syncthreads(); // tw_step, leg
     static_for<0, WSTEPS>([&](auto I) __attribute__((always_inline)) {
         constexpr int i = decltype(I)::value;
@@ -177,6 +223,7 @@ __global__ __launch_bounds__(TWO ? 2 * NT : NT, ASX_ROWSR_WAVES) void k_rows_r(c
         }
     });
     __syncthreads();
+    RSTAMP(0, task, 1);
 
     // ---- forward stage 0: butterflies j < Q0, legs Q0 apart ------------------------------------------------
     for (int j = lt; j < Q0; j += NT) {
@@ -192,6 +239,7 @@ __global__ __launch_bounds__(TWO ? 2 * NT : NT, ASX_ROWSR_WAVES) void k_rows_r(c
         static_for<0, R0>([&](auto T) __attribute__((always_inline)) { lds_put(p + decltype(T)::value * Q0, v[T]); });
     }
     __syncthreads();
+    RSTAMP(0, task, 2);
 
     // ---- wave-local: forward 1, forward 2 + X conj(Y) + inverse 2, inverse 1 -------------------------------
     for (int u0 = wave * UPW; u0 < R0; u0 += NW * UPW) { // wave-uniform trip count
@@ -233,6 +281,7 @@ __global__ __launch_bounds__(TWO ? 2 * NT : NT, ASX_ROWSR_WAVES) void k_rows_r(c
         }
     }
     __syncthreads();
+    RSTAMP(0, task, 3);
 
     // ---- inverse stage 0 from LDS, the outputs leave from registers -------------------------------------------------
     float2 *go = qo + row;
@@ -286,6 +335,10 @@ __global__ __launch_bounds__(TWO ? 2 * NT : NT, ASX_ROWSR_WAVES) void k_rows_r(c
             });
         }
     }
+    RSTAMP(0, task, 4);
+#ifdef ASX_STAMPS
+    if (P.stamps && P.stamp_kernel == 0 && threadIdx.x == 0) P.stamps[(size_t)task * 8 + 5] = wall_clock64();
+#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -320,14 +373,12 @@ static inline unsigned rcol_grid_x(int ntiles, int logT)
 // packed rows, untangling between the slots of u and M1 - u, rows u and M1 - u of C (twice its value: the factor
 // is taken back by k_rows_r) stored in natural row order.
 template <class S1, int TC, int NT>
-__global__ __launch_bounds__(NT, 4) void k_fwd_cols_r(const AsxDev *__restrict__ Pp, const float *__restrict__ src,
+__global__ __launch_bounds__(NT, 4) void k_fwd_cols_r(const RArgs P, const float *__restrict__ src,
                                                        const float *__restrict__ smp, float2 *__restrict__ cx,
                                                        float2 *__restrict__ cy, float *__restrict__ nrm_part, size_t pair_pitch)
 {
     constexpr int M1 = S1::n, T = TC, logT = asx_ilog2(TC), H = T / 2, logH = logT - 1, Q4 = T / 4, logQ4 = logT - 2;
     static_assert(T >= 4 && (M1 & 1) == 0, "four real columns per 16-byte load, an even number of packed rows");
-    const AsxDev &PD = *Pp;
-    const AsxKP P = asx_kp(PD);
     __shared__ float nrm_red[NT / 64];
     const bool is_smp = blockIdx.y != 0;
     const size_t pair = blockIdx.z;
@@ -458,28 +509,26 @@ __global__ __launch_bounds__(NT, 4) void k_fwd_cols_r(const AsxDev *__restrict__
 // Lag of component h of slot (m, g): h = 0 re0, 1 im0, 2 re1, 3 im1 -> (2m + (h & 1)) * M2 + c0 + 2g + (h >> 1).
 // ---------------------------------------------------------------------------
 template <class S1, int TC, int NT>
-__global__ __launch_bounds__(NT, 4) void k_inv_cols_r(const AsxDev *__restrict__ Pp, const float2 *__restrict__ qi, size_t pair_pitch,
+__global__ __launch_bounds__(NT, 4) void k_inv_cols_r(const RArgs P, const float2 *__restrict__ qi, size_t pair_pitch,
                                                        AsxPeakWs W, float *__restrict__ r_out)
 {
     constexpr int M1 = S1::n, T = TC, logT = asx_ilog2(TC), H = T / 2, logH = logT - 1;
-    const AsxDev &PD = *Pp;
-    const AsxKP P = asx_kp(PD);
     __shared__ asx_peak_t red[NT / 64];
     __shared__ asx_peak_t s_run0;
     __shared__ float s_b2;
     const size_t pair = blockIdx.y;
     const int tile = rcol_tile_of_block(blockIdx.x, logT);
     if (tile * T >= P.M2) return; // grid.x is rounded up; the tile width is this kernel's own (it reads only)
-    // a digitally silent track: r is exactly zero everywhere, the running maximum stays zero = index 0 (see k_inv_cols)
-    if (W.bound2[pair] == 0.f && r_out == nullptr) return;
     const double shift = W.shift ? W.shift[pair] : 0.0; // non-zero only in the second look (asx_api.hip)
     const int M2 = P.M2, c0 = tile * T;
     const float2 *in = qi + pair * pair_pitch;
     float4 *lds4 = reinterpret_cast<float4 *>(asx_lds_r);
     const LdsLayout Lc = col_layout(T, logT, NT);
+    // the pair's running maximum so far and the width of the near-maximum window: fetched now, used behind the barriers
+    const float b2_early = W.bound2[pair];
     if (threadIdx.x == 0) {
         s_run0 = W.pairmax[pair];
-        s_b2 = W.bound2[pair];
+        s_b2 = b2_early;
     }
     // ---- first stage to run (the innermost, radix RL = R_last, RL consecutive slots per butterfly), fed from HBM --------
     // Butterfly b of a column pair holds the frequencies u_b + MB t (t < RL, MB = M1 / RL, u_b = digit swap of b); their
@@ -494,6 +543,8 @@ __global__ __launch_bounds__(NT, 4) void k_inv_cols_r(const AsxDev *__restrict__
     constexpr int RL = KL.R, R0c = S1::stage(0).R, R1c = KM.R, MB = M1 / RL;
     static_assert(KL.q == 1 && MB == R0c * R1c && MB % 2 == 0, "innermost stage of consecutive slots");
     constexpr int NITEMS = (MB / 2) * H; // v = 0 takes both butterflies that pair with themselves (u_b = 0 and MB/2)
+    const size_t sblock = pair * (size_t)(P.M2 / T) + tile; (void)sblock;
+    RSTAMP(2, sblock, 0);
     const TwPre pre_mid = tw_prefetch_exec<S1, 1, true, true, true>(Lc, P.tw1);
     for (int e = threadIdx.x; e < NITEMS; e += NT) {
         const int g = e & (H - 1), v = e >> logH;  // v = u_b in [0, MB/2)
@@ -550,8 +601,14 @@ __global__ __launch_bounds__(NT, 4) void k_inv_cols_r(const AsxDev *__restrict__
             lds_put(pb + (decltype(TT)::value << logH), zb[TT]);
         });
     }
+    RSTAMP(2, sblock, 1);
+    // A digitally silent track (zero norm: r is exactly zero everywhere): the running maximum stays zero, which k_finalize
+    // reads as index 0, the reference's answer (see k_inv_cols).  Checked HERE, behind the tile loads: in front of them the
+    // block waited a memory latency for this one float before it issued anything.  Block-uniform.
+    if (b2_early == 0.f && r_out == nullptr) return;
     __syncthreads();
     const TwPre pre_last = lds_fft_static_steps<S1, true, true, S1::nstages - 1, true, 1>(lds4, Lc, P.tw1, pre_mid);
+    RSTAMP(2, sblock, 2);
     const asx_peak_t run0 = s_run0;
     const float b2 = s_b2;
     auto last_stage = [&](auto &&sink) __attribute__((always_inline)) {
@@ -599,6 +656,7 @@ __global__ __launch_bounds__(NT, 4) void k_inv_cols_r(const AsxDev *__restrict__
             });
         });
         const uint32_t my_idx = lag_of_max(gb, best_m, best_i0);
+        RSTAMP(2, sblock, 4);
         const float wmax = wave_max_nonneg(fmaxf(best_m, 0.f));
         unsigned long long holders = __ballot(best_m == wmax);
         uint32_t widx = 0xFFFFFFFFu;
@@ -613,6 +671,7 @@ __global__ __launch_bounds__(NT, 4) void k_inv_cols_r(const AsxDev *__restrict__
         asx_peak_t tb = red[0];
         for (int w = 1; w < NT / 64; w++) tb = peak_max(tb, red[w]);
         if (threadIdx.x == 0) atomicMax(&W.pairmax[pair], tb);
+        RSTAMP(2, sblock, 5);
         const float thr = near_max_threshold(peak_key(peak_max(tb, run0)), b2);
         thr_again = thr;
         if (best_m >= thr) {
@@ -652,6 +711,7 @@ __global__ __launch_bounds__(NT, 4) void k_inv_cols_r(const AsxDev *__restrict__
         thr_again = thr;
     }
     if (again) examine_again(thr_again);
+    RSTAMP(2, sblock, 3);
 }
 
 // ---------------------------------------------------------------------------
@@ -676,7 +736,7 @@ bool asx_launch_rows_r(const AsxDev &P, const float2 *cx, const float2 *cy, floa
 #define ASX_ROWSR_CASE(nt, two, n, ...)                                                                                         \
     if (P.M2 == ((two) ? 2 * n : n)) {                                                                                          \
         hipLaunchKernelGGL((k_rows_r<Sched<n, __VA_ARGS__>, nt, two>), dim3((unsigned)nrows * (unsigned)npairs),                \
-                           dim3((two) ? 2 * nt : nt), lds, s, P.self_dev, cx, cy, q, nrows, pitch, W);                          \
+                           dim3((two) ? 2 * nt : nt), lds, s, rargs_of(P), cx, cy, q, nrows, pitch, W);                          \
         return true;                                                                                                            \
     }
     ASX_ROWSR_CASE(128, false, 1200, 12, 10, 10)
@@ -726,7 +786,7 @@ bool asx_launch_fwd_cols_r(const AsxDev &P, const float *src, const float *smp, 
 #define ASX_TRY(m1, t, nt, ...)                                                                                             \
     if (P.T == (t) && ASX_RCOL_NT_OK(nt) && schedule_is_r(P.st1, m1, { __VA_ARGS__ })) {                                    \
         allow_big_lds_r((const void *)k_fwd_cols_r<Sched<m1, __VA_ARGS__>, t, nt>, lds);                                    \
-        hipLaunchKernelGGL((k_fwd_cols_r<Sched<m1, __VA_ARGS__>, t, nt>), grid, dim3(nt), lds, s, P.self_dev, src, smp, cx, cy, \
+        hipLaunchKernelGGL((k_fwd_cols_r<Sched<m1, __VA_ARGS__>, t, nt>), grid, dim3(nt), lds, s, rargs_of(P), src, smp, cx, cy, \
                            W.nrm_part, pitch);                                                                              \
         return true;                                                                                                        \
     }
@@ -749,7 +809,7 @@ bool asx_launch_inv_cols_r(const AsxDev &P, const float2 *q, const AsxPeakWs &W,
         const size_t lds = (size_t)(m1) * (t) * sizeof(float2);                                                             \
         const dim3 grid(rcol_grid_x(P.M2 / (t), asx_ilog2(t)), npairs);                                                     \
         allow_big_lds_r((const void *)k_inv_cols_r<Sched<m1, __VA_ARGS__>, t, nt>, lds);                                    \
-        hipLaunchKernelGGL((k_inv_cols_r<Sched<m1, __VA_ARGS__>, t, nt>), grid, dim3(nt), lds, s, P.self_dev, q, pitch, W, r_out); \
+        hipLaunchKernelGGL((k_inv_cols_r<Sched<m1, __VA_ARGS__>, t, nt>), grid, dim3(nt), lds, s, rargs_of(P), q, pitch, W, r_out); \
         return true;                                                                                                        \
     }
     ASX_RINV(ASX_TRY)

@@ -13,7 +13,7 @@ for p in 1 2 4 8 16 32 64; do
   /opt/rocm/bin/hipcc $F $kf $flags -DASX_PART=$p -c -o $D/k$p.o $P/csrc/xcorr_kernels.hip &
   objs="$objs $D/k$p.o"
 done
-/opt/rocm/bin/hipcc $F -mllvm -amdgpu-sched-strategy=iterative-ilp $flags -c -o $D/rlayout.o $P/csrc/rlayout.hip &
+/opt/rocm/bin/hipcc $F $flags -c -o $D/rlayout.o $P/csrc/rlayout.hip &
 /opt/rocm/bin/hipcc $F $flags -c -o $D/api.o $P/csrc/asx_api.hip &
 /opt/rocm/bin/hipcc $F $flags -c -o $D/plan.o $P/csrc/plan_math.cpp &
 /opt/rocm/bin/hipcc $F $flags -c -o $D/shard.o $P/csrc/shard_driver.cpp &
