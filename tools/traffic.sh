@@ -43,7 +43,7 @@ for k,v in calls.items():
     d=[x[1] for x in v[SKIP*per_step:(SKIP+STEPS)*per_step]] or [x[1] for x in v]
     dur[k]={'calls':len(d),'avg_ns':sum(d)/len(d),'min_ns':min(d),'max_ns':max(d)}
     rows.append((sum(d),k,len(d),sum(d)/len(d),min(d),max(d)))
-try: stamp=json.load(open(out+'/../../tools/.collect_stamp.json'))
+try: stamp=json.load(open(os.path.join(os.environ.get('GRAFT_REPO_ROOT', out+'/../../..'), 'tools', '.collect_stamp.json')))
 except Exception: stamp={}
 with open(out+'/kernel_stats_nowarm.csv','w') as fo:
     fo.write('# rocprofv3 --kernel-trace, calls of the pre-conditioned timed region only (%d untimed steps before them); head %s, kernel commit %s\n' % (max(PRE, WARMUP), stamp.get('head','?'), stamp.get('kernel_commit','?')))
