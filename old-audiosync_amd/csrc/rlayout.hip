@@ -666,6 +666,8 @@ __global__ __launch_bounds__(NT, 4) void k_inv_cols_r(const RArgs P, const float
             widx = li < widx ? li : widx;
             holders &= holders - 1;
         }
+        // (Every wave publishing its own maximum and taking its own threshold -- no block-wide reduction, no barrier here --
+        //  was measured: 0.40 -> 0.95 ms, eight times the atomics on one address per pair; profiles/r4_experiments/25_*.)
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = widx == 0xFFFFFFFFu ? 0 : peak_pack_key(wmax, widx);
         __syncthreads();
         asx_peak_t tb = red[0];
