@@ -361,9 +361,6 @@ static inline unsigned rcol_grid_x(int ntiles, int logT)
     return ((unsigned)ntiles + grp - 1) / grp * grp;
 }
 
-#ifndef ASX_RABL
-#define ASX_RABL 0 // timing ablations (wrong results): 1 fwd: plain store, no untangle; 2 inv: plain fill, no tangle; 4 fwd: 64-byte input pieces
-#endif
 #ifndef ASX_RCOL_LOADS
 #define ASX_RCOL_LOADS 5 // row-pair pieces (two 16-byte loads each) a thread keeps in flight
 #endif
@@ -403,14 +400,8 @@ __global__ __launch_bounds__(NT, 4) void k_fwd_cols_r(const RArgs P, const float
             a[I] = b[I] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (m < data_m) { // also false past the end of the tile (m >= M1 >= data_m)
                 const float *p = in + (size_t)(2 * m) * M2 + c0 + 4 * h;
-                if constexpr ((ASX_RABL & 4) != 0) { // the packed-sample kernels' pattern: one 8T-byte piece per row m
-                    const float *pp = in + 2 * ((size_t)m * M2 + c0) + 8 * h;
-                    a[I] = *reinterpret_cast<const float4 *>(pp);
-                    b[I] = *reinterpret_cast<const float4 *>(pp + 4);
-                } else {
                 a[I] = *reinterpret_cast<const float4 *>(p);
                 b[I] = *reinterpret_cast<const float4 *>(p + M2);
-                }
             }
         });
         static_for<0, ASX_RCOL_LOADS>([&](auto I) __attribute__((always_inline)) {
@@ -746,12 +737,7 @@ bool asx_launch_rows_r(const AsxDev &P, const float2 *cx, const float2 *cy, floa
     // 480-point rows: ONE wave per block -- a block is 11.5 KB of traffic and a chain of five short phases, so what counts is
     // how many are in flight: sixteen single-wave blocks per CU against eight of two waves (rows 0.93 -> 0.83 ms per 1024
     // pairs of N = 144 000, same box)
-#ifndef ASX_ROWSR_480
-#define ASX_ROWSR_480 64, false, 480, 10, 8, 6
-#endif
-#define ASX_ROWSR_CASE_X(...) ASX_ROWSR_CASE(__VA_ARGS__)
-    ASX_ROWSR_CASE_X(ASX_ROWSR_480)
-#undef ASX_ROWSR_CASE_X
+    ASX_ROWSR_CASE(64, false, 480, 10, 8, 6)
 #undef ASX_ROWSR_CASE
     return false;
 }
@@ -759,25 +745,15 @@ bool asx_launch_rows_r(const AsxDev &P, const float2 *cx, const float2 *cy, floa
 // Column schedules of the production sample lengths (plan_math.cpp's tuned table):  X(M1, tile width in real columns,
 // block size, radices...).  (1200- and 800-row tiles hold only eight real columns: 32-byte input pieces, measured 25 % slower
 // in k_fwd_cols_r, and a fed first stage of radix 10 needs 20 rows in flight per thread: the two longest lengths use 600 / 400
-// rows with 2400-point rows instead.)  Block sizes are measured (tools/dbg/nt_sweep.sh, round 4): 400-row tiles 512
+// rows with 2400-point rows instead.)  Block sizes are measured (profiles/r4_experiments/10_*, 11_*): 400-row tiles 512
 // threads (320, the packed kernels' choice: 12 % slower at N = 480 000), 300-row tiles 256 (320 / 384 / 512: 20-35 % slower).
 #define ASX_RCOLS(X) \
-    X(600, 16, 512, 10, 10, 6) X(400, 16, 512, 10, 8, 5) X(300, 16, 256, 10, 6, 5) ASX_RCOLS_EXTRA(X)
-#ifndef ASX_RCOLS_EXTRA
-#define ASX_RCOLS_EXTRA(X)
-#endif
+    X(600, 16, 512, 10, 10, 6) X(400, 16, 512, 10, 8, 5) X(300, 16, 256, 10, 6, 5)
 
 static void allow_big_lds_r(const void *fn, size_t bytes)
 {
     if (bytes > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
-
-static int rcol_nt_override()
-{
-    static const int v = getenv("ASX_RCOL_NT") ? atoi(getenv("ASX_RCOL_NT")) : 0; // diagnostic: block size of the column kernels
-    return v;
-}
-#define ASX_RCOL_NT_OK(nt) (rcol_nt_override() == 0 || rcol_nt_override() == (nt))
 
 bool asx_launch_fwd_cols_r(const AsxDev &P, const float *src, const float *smp, float2 *cx, float2 *cy, const AsxPeakWs &W,
                            int npairs, hipStream_t s)
@@ -786,7 +762,7 @@ bool asx_launch_fwd_cols_r(const AsxDev &P, const float *src, const float *smp, 
     const size_t pitch = ((size_t)P.M1 + 1) * (size_t)P.M2, lds = (size_t)P.M1 * P.T * sizeof(float2);
     const dim3 grid(rcol_grid_x(P.ntiles, P.logT), 2, npairs);
 #define ASX_TRY(m1, t, nt, ...)                                                                                             \
-    if (P.T == (t) && ASX_RCOL_NT_OK(nt) && schedule_is_r(P.st1, m1, { __VA_ARGS__ })) {                                    \
+    if (P.T == (t) && schedule_is_r(P.st1, m1, { __VA_ARGS__ })) {                                    \
         allow_big_lds_r((const void *)k_fwd_cols_r<Sched<m1, __VA_ARGS__>, t, nt>, lds);                                    \
         hipLaunchKernelGGL((k_fwd_cols_r<Sched<m1, __VA_ARGS__>, t, nt>), grid, dim3(nt), lds, s, rargs_of(P), src, smp, cx, cy, \
                            W.nrm_part, pitch);                                                                              \
@@ -797,24 +773,19 @@ bool asx_launch_fwd_cols_r(const AsxDev &P, const float *src, const float *smp, 
     return false;
 }
 
-// The inverse column kernel only reads: its tile width is its own (ASX_RINV: X(M1, width, block size, radices...)), not tied to
-// the width k_fwd_cols_r writes C with.
-#ifndef ASX_RINV
-#define ASX_RINV(X) ASX_RCOLS(X)
-#endif
 bool asx_launch_inv_cols_r(const AsxDev &P, const float2 *q, const AsxPeakWs &W, float *r_out, int npairs, hipStream_t s)
 {
     if (!P.col_pairs) return false;
     const size_t pitch = ((size_t)P.M1 + 1) * (size_t)P.M2;
 #define ASX_TRY(m1, t, nt, ...)                                                                                             \
-    if (P.M2 % (t) == 0 && ASX_RCOL_NT_OK(nt) && schedule_is_r(P.st1, m1, { __VA_ARGS__ })) {                               \
+    if (P.T == (t) && schedule_is_r(P.st1, m1, { __VA_ARGS__ })) {                               \
         const size_t lds = (size_t)(m1) * (t) * sizeof(float2);                                                             \
         const dim3 grid(rcol_grid_x(P.M2 / (t), asx_ilog2(t)), npairs);                                                     \
         allow_big_lds_r((const void *)k_inv_cols_r<Sched<m1, __VA_ARGS__>, t, nt>, lds);                                    \
         hipLaunchKernelGGL((k_inv_cols_r<Sched<m1, __VA_ARGS__>, t, nt>), grid, dim3(nt), lds, s, rargs_of(P), q, pitch, W, r_out); \
         return true;                                                                                                        \
     }
-    ASX_RINV(ASX_TRY)
+    ASX_RCOLS(ASX_TRY)
 #undef ASX_TRY
     return false;
 }
