@@ -122,6 +122,7 @@ struct asx_plan {
     } big;
     // pairs whose near-tie list overflowed since the list was last emptied (k_finalize appends, resolve_overflows reads)
     uint32_t *over_list = nullptr, *over_n = nullptr;
+    volatile uint32_t *h_over_n = nullptr; // page-locked host mirror of *over_n (device-visible: AsxPeakWs::over_host)
     size_t over_cap = 0;
     std::vector<uint32_t> h_over;
     unsigned long long repaired = 0;   // pairs that took the second look
@@ -242,9 +243,19 @@ static int plan_init(asx_plan *p, size_t N, size_t max_batch, const char *split)
     p->over_cap = std::max<size_t>(g * (size_t)p->nlanes, 1024);
     if (dev_alloc(p, &p->over_list, p->over_cap) || dev_alloc(p, &p->over_n, 1)) return -1;
     HIP_TRY(hipMemset(p->over_n, 0, sizeof(uint32_t)));
+    uint32_t *d_over_host = nullptr;
+    {
+        void *h = nullptr, *dptr = nullptr;
+        HIP_TRY(hipHostMalloc(&h, sizeof(uint32_t), hipHostMallocMapped));
+        p->h_over_n = (volatile uint32_t *)h;
+        *p->h_over_n = 0;
+        HIP_TRY(hipHostGetDevicePointer(&dptr, h, 0));
+        d_over_host = (uint32_t *)dptr;
+    }
     for (int l = 0; l < p->nlanes; l++) {
         p->lanes[l].pk.over_list = p->over_list;
         p->lanes[l].pk.over_n = p->over_n;
+        p->lanes[l].pk.over_host = d_over_host;
         p->lanes[l].pk.over_cap = (uint32_t)p->over_cap;
     }
     if (const char *e = getenv("ASX_EXACT")) p->exact = atoi(e) != 0; // initial value of asx_plan_set_exact (A/B of its cost)
@@ -391,6 +402,7 @@ extern "C" void asx_plan_destroy(asx_plan *p)
         for (hipEvent_t ev : ring) (void)hipEventDestroy(ev);
     for (void *a : p->allocs) (void)hipFree(a);
     if (p->pin32) (void)hipHostFree(p->pin32);
+    if (p->h_over_n) (void)hipHostFree((void *)p->h_over_n);
     (void)hipSetDevice(prev);
     delete p;
 }
@@ -437,6 +449,7 @@ extern "C" int asx_plan_set_exact(asx_plan *p, int on)
     for (int l = 0; l < p->nlanes; l++) HIP_TRY(hipStreamSynchronize(p->lanes[l].stream));
     HIP_TRY(hipStreamSynchronize(p->stream));
     HIP_TRY(hipMemset(p->over_n, 0, sizeof(uint32_t)));
+    *p->h_over_n = 0;
     p->exact = on != 0;
     return 0;
 }
@@ -604,7 +617,7 @@ static int second_look(asx_plan *p, size_t i, const float *f_smp, const TIn *p_s
     K.cand_n = B.cand_n; K.cand = B.cand; // ... with lists for all 2N lags: this look cannot overflow
     K.refine_n = B.refine_n; K.refine_idx = B.refine_idx; K.refine_val = B.refine_val;
     K.overflows = B.overflows;
-    K.over_list = nullptr; K.over_n = nullptr; K.over_cap = 0;
+    K.over_list = nullptr; K.over_n = nullptr; K.over_host = nullptr; K.over_cap = 0;
     K.cap = (uint32_t)B.cap;
     HIP_TRY(hipMemsetAsync(B.cand_n, 0, sizeof(uint32_t), s));
     // r = r' + stats[2]
@@ -632,23 +645,26 @@ static int second_look(asx_plan *p, size_t i, const float *f_smp, const TIn *p_s
     return 0;
 }
 
+// Returns -1 on error, else the number of pairs that took the second look.  Waits for everything the caller has enqueued
+// on `s` (its result copies included): ONE synchronisation; the count is read from the page-locked mirror k_finalize adds to
+// only when a pair overflows -- no device-to-host copy sits between the last kernel and the host.
 template <typename TIn>
 static int resolve_overflows(asx_plan *p, const float *f_smp, const TIn *p_src, const TIn *p_smp, int64_t *d_lag,
                              double *d_coef, int32_t *d_ret, hipStream_t s)
 {
-    if (p->lanes[0].pk.cap >= 2 * p->host.N) return 0; // the ordinary list already holds every lag
-    uint32_t n = 0;
-    HIP_TRY(hipMemcpyAsync(&n, p->over_n, sizeof(n), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    if (p->lanes[0].pk.cap >= 2 * p->host.N) return 0; // the ordinary list already holds every lag
+    const uint32_t n = *p->h_over_n;
     if (n == 0) return 0;
     if (n > p->over_cap) return fail("internal: %u overflowed pairs in a window of %zu", n, p->over_cap);
     p->h_over.resize(n);
     HIP_TRY(hipMemcpyAsync(p->h_over.data(), p->over_list, n * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemsetAsync(p->over_n, 0, sizeof(uint32_t), s));
     HIP_TRY(hipStreamSynchronize(s));
+    *p->h_over_n = 0;
     for (uint32_t k = 0; k < n; k++)
         if (second_look<TIn>(p, p->h_over[k], f_smp, p_src, p_smp, d_lag, d_coef, d_ret, s)) return -1;
-    return 0;
+    return (int)n;
 }
 
 extern "C" int asx_xcorr_batch_f32_dev(asx_plan *p, const float *d_source, const float *d_sample,
@@ -695,7 +711,7 @@ extern "C" int asx_xcorr_batch_f32_dev(asx_plan *p, const float *d_source, const
         // the second look, behind the window's last group (one host synchronisation per window)
         if (p->exact &&
             resolve_overflows<float>(p, d_sample + w0 * N, d_source + w0 * 2 * N, d_sample + w0 * N,
-                                     d_lag ? d_lag + w0 : nullptr, d_coef + w0, d_ret ? d_ret + w0 : nullptr, s))
+                                     d_lag ? d_lag + w0 : nullptr, d_coef + w0, d_ret ? d_ret + w0 : nullptr, s) < 0)
             return -1;
     }
     prof_end_call(p, gi);
@@ -745,11 +761,16 @@ extern "C" int asx_xcorr_batch_f32(asx_plan *p, const float *source, const float
         if (run_group<float>(p, p->st_src, p->st_smp, p->st_src, p->st_smp, g, p->st_lag, p->st_coef,
                              p->st_ret, nullptr, s, 0))
             return -1;
-        if (resolve_overflows<float>(p, p->st_smp, p->st_src, p->st_smp, p->st_lag, p->st_coef, p->st_ret, s)) return -1;
-        HIP_TRY(hipMemcpyAsync(lag + done, p->st_lag, g * sizeof(int64_t), hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipMemcpyAsync(coef + done, p->st_coef, g * sizeof(double), hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipMemcpyAsync(ret + done, p->st_ret, g * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
+        // the results come back with the same synchronisation that looks at the overflow list; again behind a second look
+        for (int pass = 0; pass < 2; pass++) {
+            HIP_TRY(hipMemcpyAsync(lag + done, p->st_lag, g * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipMemcpyAsync(coef + done, p->st_coef, g * sizeof(double), hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipMemcpyAsync(ret + done, p->st_ret, g * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+            if (pass == 1) { HIP_TRY(hipStreamSynchronize(s)); break; }
+            const int looked = resolve_overflows<float>(p, p->st_smp, p->st_src, p->st_smp, p->st_lag, p->st_coef, p->st_ret, s);
+            if (looked < 0) return -1;
+            if (looked == 0) break;
+        }
     }
     return 0;
 }
@@ -1024,7 +1045,6 @@ extern "C" int asx_xcorr_f64(asx_plan *p, const double *source, const double *sa
         p->narrowed++;
         if (run_group<float>(p, p->st_src, p->st_smp, p->st_src, p->st_smp, 1, p->st_lag, p->st_coef, p->st_ret, nullptr, s, 0))
             return -1;
-        if (resolve_overflows<float>(p, p->st_smp, p->st_src, p->st_smp, p->st_lag, p->st_coef, p->st_ret, s)) return -1;
     } else {
     HIP_TRY(hipMemcpyAsync(p->st_src64, source, 2 * N * sizeof(double), hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(p->st_smp64, sample, N * sizeof(double), hipMemcpyHostToDevice, s));
@@ -1033,15 +1053,21 @@ extern "C" int asx_xcorr_f64(asx_plan *p, const double *source, const double *sa
     if (run_group<double>(p, p->st_src, p->st_smp, p->st_src64, p->st_smp64, 1, p->st_lag, p->st_coef,
                           p->st_ret, nullptr, s, 0))
         return -1;
-    if (resolve_overflows<double>(p, p->st_smp, p->st_src64, p->st_smp64, p->st_lag, p->st_coef, p->st_ret, s)) return -1;
     }
     int64_t h_lag = 0;
     double h_coef = 0;
     int32_t h_ret = -1;
-    HIP_TRY(hipMemcpyAsync(&h_lag, p->st_lag, sizeof(h_lag), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(&h_coef, p->st_coef, sizeof(h_coef), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(&h_ret, p->st_ret, sizeof(h_ret), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    // the result comes back with the same synchronisation that looks at the overflow list; again behind a second look
+    for (int pass = 0; pass < 2; pass++) {
+        HIP_TRY(hipMemcpyAsync(&h_lag, p->st_lag, sizeof(h_lag), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(&h_coef, p->st_coef, sizeof(h_coef), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(&h_ret, p->st_ret, sizeof(h_ret), hipMemcpyDeviceToHost, s));
+        if (pass == 1) { HIP_TRY(hipStreamSynchronize(s)); break; }
+        const int looked = narrow == 1 ? resolve_overflows<float>(p, p->st_smp, p->st_src, p->st_smp, p->st_lag, p->st_coef, p->st_ret, s)
+                                       : resolve_overflows<double>(p, p->st_smp, p->st_src64, p->st_smp64, p->st_lag, p->st_coef, p->st_ret, s);
+        if (looked < 0) return -1;
+        if (looked == 0) break;
+    }
     *lag = (long)h_lag;
     *coefficient = h_coef;
     return h_ret;
@@ -1258,14 +1284,18 @@ extern "C" int asx_stream_xcorr(asx_stream *st, size_t sample_len, long *lag, do
     if (run_group<double>(p, st->src32, st->smp32, st->src64, st->smp64, 1, st->d_lag, st->d_coef, st->d_ret,
                           nullptr, s, 0))
         return -1;
-    if (resolve_overflows<double>(p, st->smp32, st->src64, st->smp64, st->d_lag, st->d_coef, st->d_ret, s)) return -1;
     int64_t h_lag = 0;
     double h_coef = 0;
     int32_t h_ret = -1;
-    HIP_TRY(hipMemcpyAsync(&h_lag, st->d_lag, sizeof(h_lag), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(&h_coef, st->d_coef, sizeof(h_coef), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(&h_ret, st->d_ret, sizeof(h_ret), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    for (int pass = 0; pass < 2; pass++) { // as in asx_xcorr_f64
+        HIP_TRY(hipMemcpyAsync(&h_lag, st->d_lag, sizeof(h_lag), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(&h_coef, st->d_coef, sizeof(h_coef), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(&h_ret, st->d_ret, sizeof(h_ret), hipMemcpyDeviceToHost, s));
+        if (pass == 1) { HIP_TRY(hipStreamSynchronize(s)); break; }
+        const int looked = resolve_overflows<double>(p, st->smp32, st->src64, st->smp64, st->d_lag, st->d_coef, st->d_ret, s);
+        if (looked < 0) return -1;
+        if (looked == 0) break;
+    }
     *lag = (long)h_lag;
     *coefficient = h_coef;
     return h_ret;

@@ -114,6 +114,8 @@ struct AsxPeakWs {
     unsigned long long *overflows; // [1] pairs whose candidate list did not fit, cumulative
     uint32_t *over_list;   // [over_cap] or null: indices (pair_base + pair) of those pairs since the list was last emptied --
     uint32_t *over_n;      // [1] ... and their number: what the entry points read to take the second look (asx_api.hip)
+    uint32_t *over_host;   // [1] or null: the same count in page-locked HOST memory (system-scope add, only when a pair overflows):
+                           // the entry points read it behind a stream synchronisation, with no device-to-host copy in the way
     uint32_t over_cap;
     const double *shift;   // [pairs] or null: c with r[k] = (what the transforms deliver) + c for every k -- the second look at a pair
                            // runs the transforms on (source - mean), see second_look (asx_api.hip); null / 0 everywhere else

@@ -922,6 +922,7 @@ __global__ __launch_bounds__(ASX_THREADS) void k_finalize(const AsxDev *__restri
             if (W.over_list) {
                 const uint32_t slot = atomicAdd(W.over_n, 1u);
                 if (slot < W.over_cap) W.over_list[slot] = pair_base + (uint32_t)pair;
+                if (W.over_host) (void)__hip_atomic_fetch_add(W.over_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
     }
