@@ -135,7 +135,9 @@ def test_device_generator_is_bit_identical(mod, torch, n, shift):
 
 # ---- the raw correlation r[k] against the oracle's ---------------------------------------
 
-@pytest.mark.parametrize("n", [6, 45, 1000, 4096, 48000, 144000])
+# (144 000 / 480 000 / 960 000: the three shapes of the real-column kernels -- single-wave 480-point rows, 1200-point rows,
+#  2400-point rows in two halves; 300- and 400-row column tiles)
+@pytest.mark.parametrize("n", [6, 45, 1000, 4096, 48000, 144000, 480000, 960000])
 def test_raw_correlation_matches_oracle(mod, torch, n):
     src, smp, _ = oracle.synth_pair(5, 1, n, 1)
     o_ret, o_lag, o_coef, o_r, margin = oracle.cross_correlation(src, smp, want_results=True)
@@ -155,6 +157,32 @@ def test_raw_correlation_matches_oracle(mod, torch, n):
     assert err < 2e-5, err   # float32 transforms; the peak margin is >= 4
     assert int(d_lag[0]) == o_lag and int(d_ret[0]) == o_ret
     assert abs(float(d_coef[0]) - o_coef) < COEF_TOL
+
+
+@pytest.mark.parametrize("n", [144000, 288000, 720000, 1440000])
+def test_both_decompositions_give_the_same_correlation(mod, torch, monkeypatch, n):
+    """the real-column kernels (csrc/rlayout.hip, default for the reference's six lengths) against the packed-sample kernels
+    (csrc/xcorr_kernels.hip, $ASX_LAYOUT=packed, read when a plan is created): the same r[k] up to float32 rounding of two
+    different evaluation orders, the same lag, the same coefficient bits (the float64 passes read the inputs, not r)"""
+    src, smp, true_lag = oracle.synth_pair(17, 2, n, 1)
+    d_src = torch.from_numpy(src).cuda(); d_smp = torch.from_numpy(smp).cuda()
+    out = {}
+    for layout in ("real-column", "packed"):
+        if layout == "packed":
+            monkeypatch.setenv("ASX_LAYOUT", "packed")
+        else:
+            monkeypatch.delenv("ASX_LAYOUT", raising=False)
+        d_r = torch.zeros(2 * n, dtype=torch.float32, device="cuda")
+        d_lag = torch.zeros(1, dtype=torch.int64, device="cuda"); d_coef = torch.zeros(1, dtype=torch.float64, device="cuda")
+        d_ret = torch.zeros(1, dtype=torch.int32, device="cuda")
+        with mod.Plan(n, 1, 0) as plan:
+            assert plan.layout == layout
+            plan.debug_r_dev(d_src.data_ptr(), d_smp.data_ptr(), d_r.data_ptr(), d_lag.data_ptr(), d_coef.data_ptr(), d_ret.data_ptr())
+            plan.sync()
+        out[layout] = (d_r.cpu().numpy().astype(np.float64), int(d_lag[0]), float(d_coef[0]), int(d_ret[0]))
+    ra, rb = out["real-column"][0], out["packed"][0]
+    assert np.abs(ra - rb).max() < 2e-5 * np.abs(rb).max()
+    assert out["real-column"][1:] == out["packed"][1:] and out["packed"][1] == true_lag
 
 
 # ---- batches on the float32 path ------------------------------------------------------------
