@@ -164,3 +164,25 @@ def test_collapsed_combine_equals_step_by_step():
         Gm = (Pm + np.conj(Pk)) - 1j * w * (Pm - np.conj(Pk))
         Ck, Cm = model.combine_pair_collapsed(ax, bx, ay, by, k, M)
         assert abs(Ck - Gk) < 1e-12 and abs(Cm - Gm) < 1e-12
+
+
+@pytest.mark.parametrize("n", [144000, 1440000])
+def test_production_length_r_matches_exact_time_domain_sums(n):
+    """An FFT-free pin of the oracle at the reference's interval lengths (the reference's own vectors stop at N = 1000,
+    tests/test_cross_correlation.c:83-113): r[k] = sum_n source[(n + k) mod 2N] * sample[n] -- the identity behind
+    src/cross_correlation.c:232-239 -- evaluated directly in extended precision at the winning lag, its neighbours, both
+    ends, the wrap-around seam and a few random lags.  The oracle's transform-based r must agree to float64 rounding of
+    a length-2N transform, and its argmax must be the lag the generator planted."""
+    src, smp, true_lag = oracle.synth_pair(77, 4, n, 1)
+    ret, lag, coef, r, margin = oracle.cross_correlation(src, smp, want_results=True)
+    assert ret == 0 and lag == true_lag and margin > 1.5
+    peak = lag if lag >= 0 else lag + 2 * n           # index into r[0 .. 2N): negative lags wrap (src/cross_correlation.c:256-263)
+    rng = np.random.default_rng(n)
+    lags = sorted({0, 1, n - 1, n, n + 1, 2 * n - 1, peak, (peak + 1) % (2 * n), (peak - 1) % (2 * n)} | {int(x) for x in rng.integers(0, 2 * n, 8)})
+    s = src.astype(np.longdouble); t = smp.astype(np.longdouble)
+    scale = float(np.sqrt((s * s).sum()) * np.sqrt((t * t).sum()))
+    for k in lags:
+        direct = float((np.roll(s, -k)[:n] * t).sum())
+        # the oracle's r is FFTW's unnormalised c2r output: 2N times the plain sum (src/cross_correlation.c:237-239)
+        assert abs(r[k] / (2.0 * n) - direct) <= 1e-12 * scale, (n, k, r[k] / (2.0 * n), direct)
+    assert abs(r[peak]) == np.abs(r).max()
