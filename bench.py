@@ -545,8 +545,11 @@ def run_rank(args, cpu=None):
             # each other (which is ahead changes with the physical placement of a process's buffers), so among kernels within
             # 10 % of the longest the one with the LOWER roofline fraction is reported: the conservative reading
             longest = max(med[k] for k in ("fwd_cols", "rows", "inv_cols", "pearson"))
-            dom = min((k for k in ("fwd_cols", "rows", "inv_cols", "pearson") if med[k] >= 0.9 * longest and ALGO_SHARE[k] > 0),
-                      key=lambda k: ALGO_SHARE[k] / med[k])
+            shared = [k for k in ("fwd_cols", "rows", "inv_cols", "pearson") if ALGO_SHARE[k] > 0]
+            near = [k for k in shared if med[k] >= 0.9 * longest]
+            # (k_inv_cols has no algorithmic share -- Q is the intermediate; should it ever be the longest kernel with nothing
+            # near it, the longest kernel that has a share is reported)
+            dom = min(near, key=lambda k: ALGO_SHARE[k] / med[k]) if near else max(shared, key=lambda k: med[k])
             dom_launch_ms = med[dom] / groups
             dom_bytes = ALGO_SHARE[dom] * n * per_launch_pairs
             achieved = dom_bytes / (dom_launch_ms * 1e-3) / 1e9

@@ -127,6 +127,7 @@ struct asx_plan {
     std::vector<uint32_t> h_over;
     unsigned long long repaired = 0;   // pairs that took the second look
     bool exact = true;                 // asx_plan_set_exact: every entry point takes the second look (default)
+    bool q_inplace = false;            // k_rows_r writes Q over the rows of C_x it has just read (rlayout only)
     // staging for the host-pointer entry points (lazy)
     float *st_src = nullptr, *st_smp = nullptr;
     int64_t *st_lag = nullptr;
@@ -258,6 +259,7 @@ static int plan_init(asx_plan *p, size_t N, size_t max_batch, const char *split)
         p->lanes[l].pk.over_host = d_over_host;
         p->lanes[l].pk.over_cap = (uint32_t)p->over_cap;
     }
+    if (const char *e = getenv("ASX_Q_INPLACE")) p->q_inplace = atoi(e) != 0 && d.rlayout;
     if (const char *e = getenv("ASX_EXACT")) p->exact = atoi(e) != 0; // initial value of asx_plan_set_exact (A/B of its cost)
     HIP_TRY(hipEventCreateWithFlags(&p->fork, hipEventDisableTiming));
     d.stamps = nullptr;
@@ -445,9 +447,10 @@ extern "C" int asx_plan_set_exact(asx_plan *p, int on)
     std::lock_guard<std::mutex> guard(p->lock);
     DevGuard dg(p->device);
     if (!dg.ok) return fail("cannot select device %d", p->device);
-    // whatever the asynchronous mode left on the list belongs to calls that have returned: start empty
-    for (int l = 0; l < p->nlanes; l++) HIP_TRY(hipStreamSynchronize(p->lanes[l].stream));
-    HIP_TRY(hipStreamSynchronize(p->stream));
+    // whatever the asynchronous mode left on the list belongs to calls that have returned: start empty.  The whole
+    // device is drained, not only the plan's own streams: an asynchronous batch may still be in flight on a stream the
+    // CALLER supplied (asx_xcorr_batch_f32_dev's `stream`), and its k_finalize adds to the count this resets.
+    HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemset(p->over_n, 0, sizeof(uint32_t)));
     *p->h_over_n = 0;
     p->exact = on != 0;
@@ -547,19 +550,26 @@ static int prof_mark(asx_plan *p, hipStream_t s, size_t slot)
 template <typename TIn>
 static int run_group(asx_plan *p, const float *d_src, const float *d_smp, const TIn *p_src,
                      const TIn *p_smp, size_t g, int64_t *d_lag, double *d_coef, int32_t *d_ret,
-                     float *d_r, hipStream_t s, size_t group_index, int lane = 0, uint32_t pair_base = 0)
+                     float *d_r, hipStream_t s, size_t group_index, int lane = 0, uint32_t pair_base = 0, bool listed = true)
 {
     const AsxDev &P = p->dev;
     asx_plan::Lane &W = p->lanes[lane];
+    // `listed`: the caller reads the plan's overflow list behind this group (resolve_overflows).  A caller that does not
+    // (the asynchronous mode) must not leave entries on it either: their indices count from ITS buffers, and the next
+    // synchronous call would take a second look at its own staging buffers with them.  Marked and counted
+    // (ASX_SEG_INEXACT -> ret = 1, asx_plan_peak_overflows) they still are.
+    AsxPeakWs fin = W.pk;
+    if (!listed) { fin.over_list = nullptr; fin.over_n = nullptr; fin.over_host = nullptr; fin.over_cap = 0; }
     const size_t e0 = group_index * 6;
     if (prof_mark(p, s, e0 + 0)) return -1;
     asx_launch_fwd_cols(P, d_src, d_smp, W.zxa, W.zya, W.pk, (int)g, s);
     if (prof_mark(p, s, e0 + 1)) return -1;
-    asx_launch_rows(P, W.zxa, W.zya, W.ga, W.pk, (int)g, s);
+    float2 *q = p->q_inplace ? W.zxa : W.ga;
+    asx_launch_rows(P, W.zxa, W.zya, q, W.pk, (int)g, s);
     if (prof_mark(p, s, e0 + 2)) return -1;
-    asx_launch_inv_cols(P, W.ga, W.pk, d_r, (int)g, s);
+    asx_launch_inv_cols(P, q, W.pk, d_r, (int)g, s);
     if (prof_mark(p, s, e0 + 3)) return -1;
-    asx_launch_finalize(P, W.pk, W.seg, (int)g, s, pair_base);
+    asx_launch_finalize(P, fin, W.seg, (int)g, s, pair_base);
     if (sizeof(TIn) == sizeof(float))
         asx_launch_refine_f32(P, (const float *)p_src, (const float *)p_smp, W.pk, W.seg, (int)g, s);
     else
@@ -656,7 +666,13 @@ static int resolve_overflows(asx_plan *p, const float *f_smp, const TIn *p_src, 
     if (p->lanes[0].pk.cap >= 2 * p->host.N) return 0; // the ordinary list already holds every lag
     const uint32_t n = *p->h_over_n;
     if (n == 0) return 0;
-    if (n > p->over_cap) return fail("internal: %u overflowed pairs in a window of %zu", n, p->over_cap);
+    if (n > p->over_cap) {
+        // cannot happen (a window is at most over_cap pairs); if it ever does, the list must not stay poisoned
+        (void)hipMemsetAsync(p->over_n, 0, sizeof(uint32_t), s);
+        (void)hipStreamSynchronize(s);
+        *p->h_over_n = 0;
+        return fail("internal: %u overflowed pairs in a window of %zu", n, p->over_cap);
+    }
     p->h_over.resize(n);
     HIP_TRY(hipMemcpyAsync(p->h_over.data(), p->over_list, n * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemsetAsync(p->over_n, 0, sizeof(uint32_t), s));
@@ -699,7 +715,7 @@ extern "C" int asx_xcorr_batch_f32_dev(asx_plan *p, const float *d_source, const
             hipStream_t ls = overlap ? p->lanes[lane].stream : s;
             if (run_group<float>(p, d_source + done * 2 * N, d_sample + done * N, d_source + done * 2 * N,
                                  d_sample + done * N, g, d_lag ? d_lag + done : nullptr, d_coef + done,
-                                 d_ret ? d_ret + done : nullptr, nullptr, ls, gi, lane, (uint32_t)(done - w0)))
+                                 d_ret ? d_ret + done : nullptr, nullptr, ls, gi, lane, (uint32_t)(done - w0), p->exact))
                 return -1;
         }
         if (overlap) {
@@ -728,8 +744,10 @@ extern "C" int asx_xcorr_debug_r_dev(asx_plan *p, const float *d_source, const f
     if (!dg.ok) return fail("cannot select device %d", p->device);
     hipStream_t s = stream ? (hipStream_t)stream : p->stream;
     prof_begin_call(p);
-    const int rc = run_group<float>(p, d_source, d_sample, d_source, d_sample, 1, d_lag, d_coef, d_ret, d_r, s, 0);
+    // like every other entry point: listed and looked at again in the exact mode, only marked (ret = 1) otherwise
+    int rc = run_group<float>(p, d_source, d_sample, d_source, d_sample, 1, d_lag, d_coef, d_ret, d_r, s, 0, 0, 0, p->exact);
     prof_end_call(p, 1);
+    if (rc == 0 && p->exact && resolve_overflows<float>(p, d_sample, d_source, d_sample, d_lag, d_coef, d_ret, s) < 0) rc = -1;
     return rc;
 }
 

@@ -97,6 +97,20 @@ __device__ __forceinline__ void wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Diagnostic builds only (tools/mkr.sh; never defined in the shipped library):
+//   -DASX_EXP_PAIRMOD=<m>   every pair of a launch uses the C / Q workspaces of pair (pair % m): wrong results, the traffic
+//                           of a launch whose intermediates never leave the 256 MiB Infinity Cache (upper bound of keeping
+//                           them on die, EXPERIMENTS.md)
+//   -DASX_ROWS2_SCHED=a,b,c the radix schedule of the 1200-point sub-rows of the two-half row kernel
+#ifdef ASX_EXP_PAIRMOD
+#define RWS_PAIR(pair) ((pair) % (ASX_EXP_PAIRMOD))
+#else
+#define RWS_PAIR(pair) (pair)
+#endif
+#ifndef ASX_ROWS2_SCHED
+#define ASX_ROWS2_SCHED 12, 10, 10
+#endif
+
 #ifndef ASX_ROWSR_WAVES
 #define ASX_ROWSR_WAVES 4 // waves per SIMD the register allocation must allow: 8 blocks of 2 waves per CU
 #endif
@@ -147,7 +161,7 @@ __global__ __launch_bounds__(TWO ? 2 * NT : NT, ASX_ROWSR_WAVES) void k_rows_r(c
 
     const int pair = task / nrows;
     const uint32_t k1 = (uint32_t)(task - pair * nrows);
-    const size_t row = (size_t)pair * pair_pitch + (size_t)k1 * M2;
+    const size_t row = (size_t)RWS_PAIR(pair) * pair_pitch + (size_t)k1 * M2;
     if (k1 == 0 && tid < 64) {
         // Row 0 of a pair also prepares the pair's peak search (k_inv_cols_r runs after this kernel): the float32
         // error bound from the norms k_fwd_cols_r left, the running maximum and the candidate count back to zero.
@@ -348,7 +362,7 @@ __global__ __launch_bounds__(TWO ? 2 * NT : NT, ASX_ROWSR_WAVES) void k_rows_r(c
 // of lds_fft.h).  A tile row is 4T bytes of the input (32 / T tiles share a 128-byte line: blocks b, b+8, ... of
 // one XCD, as in col_tile_of_block) and 8T bytes of C / Q.
 // ---------------------------------------------------------------------------
-__device__ __host__ __forceinline__ int rcol_line_log(int logT) { return logT >= 5 ? 0 : 5 - logT; } // log2(tiles per input line)
+__device__ __host__ constexpr int rcol_line_log(int logT) { return logT >= 5 ? 0 : 5 - logT; } // log2(tiles per input line)
 __device__ __forceinline__ int rcol_tile_of_block(int b, int logT)
 {
     const int ll = rcol_line_log(logT);
@@ -380,11 +394,12 @@ __global__ __launch_bounds__(NT, 4) void k_fwd_cols_r(const RArgs P, const float
     const bool is_smp = blockIdx.y != 0;
     const size_t pair = blockIdx.z;
     const int tile = rcol_tile_of_block(blockIdx.x, logT);
+    const unsigned which = blockIdx.y;
     if (tile >= P.ntiles) return; // grid.x is rounded up
     const int M2 = P.M2, c0 = tile * T;
     const float *in = is_smp ? smp + pair * (size_t)P.N : src + pair * (size_t)(2u * P.N);
     const int data_m = is_smp ? M1 / 2 : M1; // packed rows that are not zero padding
-    float2 *out = (is_smp ? cy : cx) + pair * pair_pitch;
+    float2 *out = (is_smp ? cy : cx) + RWS_PAIR(pair) * pair_pitch;
     float4 *lds4 = reinterpret_cast<float4 *>(asx_lds_r);
     const LdsLayout Lc = col_layout(T, logT, NT);
     const TwPre pre = tw_prefetch_first<S1, false, true>(Lc, P.tw1);
@@ -425,7 +440,7 @@ __global__ __launch_bounds__(NT, 4) void k_fwd_cols_r(const RArgs P, const float
     if (threadIdx.x == 0) {
         float t = nrm_red[0];
         for (int w = 1; w < NT / 64; w++) t += nrm_red[w];
-        nrm_part[(pair * 2 + blockIdx.y) * (size_t)P.ntiles + tile] = t;
+        nrm_part[(pair * 2 + which) * (size_t)P.ntiles + tile] = t;
     }
     // ---- the innermost stage (radix RL, RL consecutive slots per butterfly, no twiddles), untangling and the stores, all
     // from registers.  Butterfly b of a column pair yields the frequencies u_b + MB t (t < RL, MB = M1 / RL, u_b = digit
@@ -492,7 +507,7 @@ __global__ __launch_bounds__(NT, 4) void k_fwd_cols_r(const RArgs P, const float
 }
 
 // ---------------------------------------------------------------------------
-// k_inv_cols_r: grid (tiles, npairs).  c2r column transforms of length 2 M1 from the rows k1 = 0 .. M1 of Q: tangling
+// k_inv_cols_r: grid (npairs, tiles).  c2r column transforms of length 2 M1 from the rows k1 = 0 .. M1 of Q: tangling
 // between rows u and M1 - u into the slots of the M1-point inverse transform, whose outputs are the packed rows
 // z[m] = r[2m] + i r[2m+1] of the tile's T real columns; the last stage is consumed from registers (r reaches
 // neither HBM nor LDS): |.|-argmax with the reference's tie / sign / NaN rules (src/cross_correlation.c:52-67),
@@ -507,12 +522,17 @@ __global__ __launch_bounds__(NT, 4) void k_inv_cols_r(const RArgs P, const float
     __shared__ asx_peak_t red[NT / 64];
     __shared__ asx_peak_t s_run0;
     __shared__ float s_b2;
-    const size_t pair = blockIdx.y;
-    const int tile = rcol_tile_of_block(blockIdx.x, logT);
-    if (tile * T >= P.M2) return; // grid.x is rounded up; the tile width is this kernel's own (it reads only)
+    // TILE-major launch order, grid (npairs, tiles): the tiles of one pair are spread over the life of the launch, so the running
+    // maximum a block fetches at its start (`run0`) already holds the maximum of the tiles before it, and a tile that cannot hold
+    // the peak -- nearly all of them -- never enters the candidate path with its returning atomic.  Pair-major (the 150 tiles of a
+    // pair resident together, run0 == 0 for all of them): 0.405 against 0.367 ms at 600 rows, 0.423 against 0.299 ms per 1024 pairs
+    // at 300 rows (profiles/r5_experiments/02_*).
+    const size_t pair = blockIdx.x;
+    const int tile = rcol_tile_of_block(blockIdx.y, logT);
+    if (tile * T >= P.M2) return; // the tile count is rounded up; the tile width is this kernel's own (it reads only)
     const double shift = W.shift ? W.shift[pair] : 0.0; // non-zero only in the second look (asx_api.hip)
     const int M2 = P.M2, c0 = tile * T;
-    const float2 *in = qi + pair * pair_pitch;
+    const float2 *in = qi + RWS_PAIR(pair) * pair_pitch;
     float4 *lds4 = reinterpret_cast<float4 *>(asx_lds_r);
     const LdsLayout Lc = col_layout(T, logT, NT);
     // the pair's running maximum so far and the width of the near-maximum window: fetched now, used behind the barriers
@@ -658,7 +678,9 @@ __global__ __launch_bounds__(NT, 4) void k_inv_cols_r(const RArgs P, const float
             holders &= holders - 1;
         }
         // (Every wave publishing its own maximum and taking its own threshold -- no block-wide reduction, no barrier here --
-        //  was measured: 0.40 -> 0.95 ms, eight times the atomics on one address per pair; profiles/r4_experiments/25_*.)
+        //  was measured: 0.40 -> 0.95 ms, eight times the atomics on one address per pair; profiles/r4_experiments/25_*.  With the
+        //  tile-major order and a per-wave exit below run0's window it costs nothing and gains nothing: 0.366 against 0.367 ms,
+        //  profiles/r5_experiments/02_*.)
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = widx == 0xFFFFFFFFu ? 0 : peak_pack_key(wmax, widx);
         __syncthreads();
         asx_peak_t tb = red[0];
@@ -733,7 +755,7 @@ bool asx_launch_rows_r(const AsxDev &P, const float2 *cx, const float2 *cy, floa
         return true;                                                                                                            \
     }
     ASX_ROWSR_CASE(128, false, 1200, 12, 10, 10)
-    ASX_ROWSR_CASE(128, true, 1200, 12, 10, 10)
+    ASX_ROWSR_CASE(128, true, 1200, ASX_ROWS2_SCHED)
     // 480-point rows: ONE wave per block -- a block is 11.5 KB of traffic and a chain of five short phases, so what counts is
     // how many are in flight: sixteen single-wave blocks per CU against eight of two waves (rows 0.93 -> 0.83 ms per 1024
     // pairs of N = 144 000, same box)
@@ -780,7 +802,7 @@ bool asx_launch_inv_cols_r(const AsxDev &P, const float2 *q, const AsxPeakWs &W,
 #define ASX_TRY(m1, t, nt, ...)                                                                                             \
     if (P.T == (t) && schedule_is_r(P.st1, m1, { __VA_ARGS__ })) {                               \
         const size_t lds = (size_t)(m1) * (t) * sizeof(float2);                                                             \
-        const dim3 grid(rcol_grid_x(P.M2 / (t), asx_ilog2(t)), npairs);                                                     \
+        const dim3 grid(npairs, rcol_grid_x(P.M2 / (t), asx_ilog2(t)));                                                     \
         allow_big_lds_r((const void *)k_inv_cols_r<Sched<m1, __VA_ARGS__>, t, nt>, lds);                                    \
         hipLaunchKernelGGL((k_inv_cols_r<Sched<m1, __VA_ARGS__>, t, nt>), grid, dim3(nt), lds, s, rargs_of(P), q, pitch, W, r_out); \
         return true;                                                                                                        \

@@ -234,6 +234,56 @@ def test_overflowing_pairs_in_consecutive_groups_on_two_lanes(mod, monkeypatch):
         assert abs(float(d_coef[i]) - o_coef) < 1e-5, i
 
 
+def test_asynchronous_batch_leaves_nothing_on_the_overflow_list(mod):
+    """with asx_plan_set_exact(plan, 0) a device batch only MARKS an overflowing pair (ret = 1).  The header
+    advises submitting such a pair again -- through a synchronous entry point of the same plan.  That call must look at
+    ITS OWN pairs only: the marked pair sat at an index beyond the plan's staging group, and a stale list entry would
+    have sent the second look to source + index * 2N of the staging buffers."""
+    import torch
+    n = 24000
+    rng = np.random.default_rng(5)
+    batch, group = 12, 4
+    base = rng.integers(-5, 6, 8).astype(np.float32)
+    per = np.tile(base, 2 * n // 8)
+    per_smp = np.roll(per, -3)[:n].copy()
+    srcs, smps = [], []
+    for i in range(batch):
+        if i == 9:                                  # index >= group: out of the staging buffers' range
+            srcs.append(per); smps.append(per_smp)
+        else:
+            s_, t_, _ = oracle.synth_pair(21, i, n, 1)
+            srcs.append(s_); smps.append(t_)
+    with mod.Plan(n, group, 0) as plan:
+        assert plan.group == group and plan.peak_capacity < 2 * n
+        plan.set_exact(False)
+        d_src = torch.from_numpy(np.stack(srcs)).cuda(); d_smp = torch.from_numpy(np.stack(smps)).cuda()
+        d_lag = torch.full((batch,), -99, dtype=torch.int64, device="cuda")
+        d_coef = torch.zeros(batch, dtype=torch.float64, device="cuda")
+        d_ret = torch.full((batch,), 7, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        plan.xcorr_batch_dev(d_src.data_ptr(), d_smp.data_ptr(), batch, d_lag.data_ptr(), d_coef.data_ptr(), d_ret.data_ptr())
+        plan.sync()
+        assert int(d_ret[9]) == 1 and plan.peak_overflows() == 1 and plan.peak_repairs() == 0
+        # the advised flow: the marked pair again, alone, through the synchronous entry points of the SAME plan
+        lag, coef, ret = plan.xcorr_batch_f32(per[None], per_smp[None])
+        assert plan.peak_repairs() == 1            # its own overflow, looked at once -- not the stale index 9 as well
+        o_ret, o_lag, o_coef = oracle.cross_correlation(per, per_smp)
+        assert (int(ret[0]), int(lag[0])) == (o_ret, o_lag) == (0, 3) and coef[0] == 1.0
+        # an ordinary pair through the double entry point: no second look at all
+        s_, t_, true_lag = oracle.synth_pair(21, 2, n, 1)
+        r64, l64, c64 = plan.xcorr_f64(s_.astype(np.float64), t_.astype(np.float64))
+        assert (r64, l64) == (0, true_lag) and plan.peak_repairs() == 1
+        # the debug entry point resolves (exact mode) or marks (asynchronous mode) like the others, and leaves nothing behind
+        plan.set_exact(True)
+        d_r = torch.zeros(2 * n, dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        plan.debug_r_dev(d_src[9].data_ptr(), d_smp[9].data_ptr(), d_r.data_ptr(), d_lag.data_ptr(), d_coef.data_ptr(), d_ret.data_ptr())
+        plan.sync()
+        assert plan.peak_repairs() == 2 and (int(d_ret[0]), int(d_lag[0])) == (0, 3)
+        lag2, coef2, ret2 = plan.xcorr_batch_f32(s_[None], t_[None])
+        assert plan.peak_repairs() == 2 and int(lag2[0]) == true_lag
+
+
 def test_second_look_through_the_reference_api(hostlib):
     """cross_correlation(double*) on a pair whose near-tie list overflows (source periodic in 16 frames at
     N = 96 000: 12 000 exact ties > 2 048 list entries): the second look resolves them exactly"""
