@@ -94,6 +94,23 @@ int asx_plan_peak_repairs(asx_plan *plan, uint64_t *count);
 int asx_plan_set_exact(asx_plan *plan, int on);
 size_t asx_plan_peak_capacity(const asx_plan *plan);
 
+/* The Pearson coefficient of src/cross_correlation.c:74-116 (pearson_coefficient(), :272) in the batched float32 entry
+ * points.  Two forms, the same formula:
+ *   direct    the reference's reduction over both segments (one streaming pass with the accuracy of its two);
+ *   spectral  (the default on plans for the reference's six lengths, asx_plan_layout() == 1) the cross term is r[peak] --
+ *             exactly the sum the transforms have just computed (minus, for a negative lag, the |lag| products that did not
+ *             wrap around) -- and the four window sums come from per-band sums the forward pass keeps of the samples it
+ *             loads anyway; the inputs are not read a second time.  r[peak] carries the float32 transforms' error; its
+ *             bound (the one that guards the lag) and that of the float32 band sums are turned into a bound on the
+ *             coefficient's error PER PAIR, and a pair whose bound exceeds 1e-5 (quiet windows of a loud track, large
+ *             offsets, short segments) takes the direct form by itself.  So: |coefficient - reference's| <= 1e-5 either
+ *             way; the spectral form's value is not bit-identical to the direct form's.
+ * cross_correlation(double*) / asx_xcorr_f64 / asx_stream_xcorr always use the direct form on the caller's doubles.
+ * asx_plan_pearson_modes: pairs so far that took {spectral, spectral + wrap-around correction, direct} under the spectral
+ * setting (synchronises the plan's streams). */
+int asx_plan_set_pearson(asx_plan *plan, int spectral);
+int asx_plan_pearson_modes(asx_plan *plan, uint64_t counts[3]);
+
 /* Introspection (used by tests, bench and DESIGN.md's numbers). */
 size_t asx_plan_sample_len(const asx_plan *plan);
 size_t asx_plan_fft_len(const asx_plan *plan);        /* F, real transform length */

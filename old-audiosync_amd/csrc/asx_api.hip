@@ -106,6 +106,7 @@ struct asx_plan {
         AsxPeakWs pk{};
         AsxSeg *seg = nullptr;
         double *psums = nullptr;
+        AsxSpecWs spec{};      // spectral Pearson (pearson_spectral.hip): work list, window sums, mode counters
     } lanes[2];
     int nlanes = 1;   // ASX_LANES=2 enables the second lane (measured: +0..4 %)
     hipEvent_t fork = nullptr;
@@ -127,6 +128,8 @@ struct asx_plan {
     std::vector<uint32_t> h_over;
     unsigned long long repaired = 0;   // pairs that took the second look
     bool exact = true;                 // asx_plan_set_exact: every entry point takes the second look (default)
+    bool spectral = false;             // float32 groups take the spectral Pearson form (asx_plan_set_pearson; real-column plans)
+    unsigned long long *mode_count = nullptr; // [ASX_PM_NMODES], cumulative over the plan's life
     bool q_inplace = false;            // k_rows_r writes Q over the rows of C_x it has just read (rlayout only)
     // staging for the host-pointer entry points (lazy)
     float *st_src = nullptr, *st_smp = nullptr;
@@ -196,6 +199,7 @@ static int plan_init(asx_plan *p, size_t N, size_t max_batch, const char *split)
     // schedules (the reference's six lengths); ASX_LAYOUT=packed forces the packed-sample kernels (A/B runs, the run-time-schedule
     // kernels of ASX_GENERIC)
     d.rlayout = 0;
+    d.band_rows = d.nbands = 0;
     d.col_pairs = nullptr;
     d.col_tw = nullptr;
     {
@@ -204,6 +208,8 @@ static int plan_init(asx_plan *p, size_t N, size_t max_batch, const char *split)
         if (h.rlayout && !packed) {
             if (dev_upload(p, &d.col_pairs, h.col_pairs) || dev_upload(p, &d.col_tw, h.col_tw)) return -1;
             d.rlayout = asx_rlayout_available(d) ? 1 : 0;
+            d.band_rows = d.rlayout ? asx_rlayout_band_rows(d) : 0;
+            d.nbands = d.band_rows ? 2 * h.M1 / d.band_rows : 0;
         }
     }
     // group size: keep the three inter-kernel intermediates (24*M bytes per pair) of one
@@ -236,6 +242,21 @@ static int plan_init(asx_plan *p, size_t N, size_t max_batch, const char *split)
             dev_alloc(p, &ln.seg, g) || dev_alloc(p, &ln.psums, g * (size_t)asx_pearson_blocks((uint32_t)N) * 6))
             return -1;
         HIP_TRY(hipMemset(ln.pk.overflows, 0, sizeof(unsigned long long)));
+        ln.pk.band = nullptr; ln.pk.tile_peak = nullptr;
+        if (d.rlayout) {
+            // spectral Pearson: band sums of both tracks (the sample fills the first half of its bands), one signed peak value
+            // per inverse tile, the work list and the window sums of the group's pairs
+            const size_t nbands = (size_t)d.nbands;
+            if (!p->mode_count) {
+                if (dev_alloc(p, &p->mode_count, ASX_PM_NMODES)) return -1;
+                HIP_TRY(hipMemset(p->mode_count, 0, ASX_PM_NMODES * sizeof(unsigned long long)));
+            }
+            if (dev_alloc(p, &ln.pk.band, g * 2 * nbands * (size_t)h.ntiles) || dev_alloc(p, &ln.pk.tile_peak, g * (size_t)(h.M2 / h.T)) ||
+                dev_alloc(p, &ln.spec.seg2, g) || dev_alloc(p, &ln.spec.pre, g * ASX_PRE_DOUBLES))
+                return -1;
+            ln.spec.mode_count = p->mode_count;
+            ln.spec.tol = 1e-5;
+        }
         HIP_TRY(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&ln.done, hipEventDisableTiming));
     }
@@ -259,6 +280,8 @@ static int plan_init(asx_plan *p, size_t N, size_t max_batch, const char *split)
         p->lanes[l].pk.over_host = d_over_host;
         p->lanes[l].pk.over_cap = (uint32_t)p->over_cap;
     }
+    p->spectral = d.rlayout != 0;
+    if (const char *e = getenv("ASX_PEARSON")) p->spectral = p->spectral && strcmp(e, "direct") != 0; // A/B of the two forms
     if (const char *e = getenv("ASX_Q_INPLACE")) p->q_inplace = atoi(e) != 0 && d.rlayout;
     if (const char *e = getenv("ASX_EXACT")) p->exact = atoi(e) != 0; // initial value of asx_plan_set_exact (A/B of its cost)
     HIP_TRY(hipEventCreateWithFlags(&p->fork, hipEventDisableTiming));
@@ -457,6 +480,31 @@ extern "C" int asx_plan_set_exact(asx_plan *p, int on)
     return 0;
 }
 
+extern "C" int asx_plan_set_pearson(asx_plan *p, int spectral)
+{
+    if (!p) return fail("asx_plan_set_pearson: null argument");
+    std::lock_guard<std::mutex> guard(p->lock);
+    if (spectral && !p->dev.rlayout) return fail("asx_plan_set_pearson: the spectral form needs a real-column plan (the reference's six lengths)");
+    p->spectral = spectral != 0;
+    return 0;
+}
+
+extern "C" int asx_plan_pearson_modes(asx_plan *p, uint64_t counts[3])
+{
+    if (!p || !counts) return fail("asx_plan_pearson_modes: null argument");
+    std::lock_guard<std::mutex> guard(p->lock);
+    DevGuard dg(p->device);
+    if (!dg.ok) return fail("cannot select device %d", p->device);
+    counts[0] = counts[1] = counts[2] = 0;
+    if (!p->mode_count) return 0;
+    for (int l = 0; l < p->nlanes; l++) HIP_TRY(hipStreamSynchronize(p->lanes[l].stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    unsigned long long v[ASX_PM_NMODES];
+    HIP_TRY(hipMemcpy(v, p->mode_count, sizeof v, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 3; i++) counts[i] = v[i];
+    return 0;
+}
+
 extern "C" int asx_plan_peak_repairs(asx_plan *p, uint64_t *count)
 {
     if (!p || !count) return fail("asx_plan_peak_repairs: null argument");
@@ -550,7 +598,8 @@ static int prof_mark(asx_plan *p, hipStream_t s, size_t slot)
 template <typename TIn>
 static int run_group(asx_plan *p, const float *d_src, const float *d_smp, const TIn *p_src,
                      const TIn *p_smp, size_t g, int64_t *d_lag, double *d_coef, int32_t *d_ret,
-                     float *d_r, hipStream_t s, size_t group_index, int lane = 0, uint32_t pair_base = 0, bool listed = true)
+                     float *d_r, hipStream_t s, size_t group_index, int lane = 0, uint32_t pair_base = 0, bool listed = true,
+                     bool float32_call = true)
 {
     const AsxDev &P = p->dev;
     asx_plan::Lane &W = p->lanes[lane];
@@ -560,14 +609,19 @@ static int run_group(asx_plan *p, const float *d_src, const float *d_smp, const 
     // (ASX_SEG_INEXACT -> ret = 1, asx_plan_peak_overflows) they still are.
     AsxPeakWs fin = W.pk;
     if (!listed) { fin.over_list = nullptr; fin.over_n = nullptr; fin.over_host = nullptr; fin.over_cap = 0; }
+    // The spectral Pearson form (pearson_spectral.hip): groups of float32 inputs of a float32 ENTRY POINT on a real-column plan.
+    // The double ABI keeps the float64 reduction over the caller's values even when its frames crossed PCIe as float32.
+    const bool spectral = p->spectral && sizeof(TIn) == sizeof(float) && float32_call && W.pk.band;
+    AsxPeakWs tk = W.pk; // what the transform kernels see
+    if (!spectral) { tk.band = nullptr; tk.tile_peak = nullptr; }
     const size_t e0 = group_index * 6;
     if (prof_mark(p, s, e0 + 0)) return -1;
-    asx_launch_fwd_cols(P, d_src, d_smp, W.zxa, W.zya, W.pk, (int)g, s);
+    asx_launch_fwd_cols(P, d_src, d_smp, W.zxa, W.zya, tk, (int)g, s);
     if (prof_mark(p, s, e0 + 1)) return -1;
     float2 *q = p->q_inplace ? W.zxa : W.ga;
-    asx_launch_rows(P, W.zxa, W.zya, q, W.pk, (int)g, s);
+    asx_launch_rows(P, W.zxa, W.zya, q, tk, (int)g, s);
     if (prof_mark(p, s, e0 + 2)) return -1;
-    asx_launch_inv_cols(P, q, W.pk, d_r, (int)g, s);
+    asx_launch_inv_cols(P, q, tk, d_r, (int)g, s);
     if (prof_mark(p, s, e0 + 3)) return -1;
     asx_launch_finalize(P, fin, W.seg, (int)g, s, pair_base);
     if (sizeof(TIn) == sizeof(float))
@@ -575,7 +629,10 @@ static int run_group(asx_plan *p, const float *d_src, const float *d_smp, const 
     else
         asx_launch_refine_f64(P, (const double *)p_src, (const double *)p_smp, W.pk, W.seg, (int)g, s);
     if (prof_mark(p, s, e0 + 4)) return -1;
-    if (sizeof(TIn) == sizeof(float))
+    if (spectral)
+        asx_launch_pearson_spectral_f32(P, (const float *)p_src, (const float *)p_smp, tk, W.spec, W.seg, W.psums, d_lag, d_coef,
+                                        d_ret, (int)g, s);
+    else if (sizeof(TIn) == sizeof(float))
         asx_launch_pearson_f32((const float *)p_src, (const float *)p_smp, 2 * (size_t)P.N, P.N, P.N,
                                W.seg, W.psums, d_lag, d_coef, d_ret, (int)g, s);
     else
@@ -628,6 +685,7 @@ static int second_look(asx_plan *p, size_t i, const float *f_smp, const TIn *p_s
     K.refine_n = B.refine_n; K.refine_idx = B.refine_idx; K.refine_val = B.refine_val;
     K.overflows = B.overflows;
     K.over_list = nullptr; K.over_n = nullptr; K.over_host = nullptr; K.over_cap = 0;
+    K.band = nullptr; K.tile_peak = nullptr; // the second look ends with the direct Pearson reduction
     K.cap = (uint32_t)B.cap;
     HIP_TRY(hipMemsetAsync(B.cand_n, 0, sizeof(uint32_t), s));
     // r = r' + stats[2]
@@ -745,7 +803,8 @@ extern "C" int asx_xcorr_debug_r_dev(asx_plan *p, const float *d_source, const f
     hipStream_t s = stream ? (hipStream_t)stream : p->stream;
     prof_begin_call(p);
     // like every other entry point: listed and looked at again in the exact mode, only marked (ret = 1) otherwise
-    int rc = run_group<float>(p, d_source, d_sample, d_source, d_sample, 1, d_lag, d_coef, d_ret, d_r, s, 0, 0, 0, p->exact);
+    // (the direct Pearson form: this entry point exists to compare decompositions and to dump r)
+    int rc = run_group<float>(p, d_source, d_sample, d_source, d_sample, 1, d_lag, d_coef, d_ret, d_r, s, 0, 0, 0, p->exact, false);
     prof_end_call(p, 1);
     if (rc == 0 && p->exact && resolve_overflows<float>(p, d_sample, d_source, d_sample, d_lag, d_coef, d_ret, s) < 0) rc = -1;
     return rc;
@@ -1061,7 +1120,8 @@ extern "C" int asx_xcorr_f64(asx_plan *p, const double *source, const double *sa
     }
     if (narrow == 1) {
         p->narrowed++;
-        if (run_group<float>(p, p->st_src, p->st_smp, p->st_src, p->st_smp, 1, p->st_lag, p->st_coef, p->st_ret, nullptr, s, 0))
+        if (run_group<float>(p, p->st_src, p->st_smp, p->st_src, p->st_smp, 1, p->st_lag, p->st_coef, p->st_ret, nullptr, s, 0, 0, 0,
+                             true, false))
             return -1;
     } else {
     HIP_TRY(hipMemcpyAsync(p->st_src64, source, 2 * N * sizeof(double), hipMemcpyHostToDevice, s));

@@ -72,6 +72,8 @@ struct AsxDev {
     const int *pos1_of_k1; // k1 -> row slot
     const int *pos2_of_k2; // k2 -> slot inside a row after the forward row transform
     const int4 *row_tasks; // [M1/2+1] {slot of row k1, slot of row M1-k1, k1, M1-k1}: one load starts a k_rows block
+    int band_rows, nbands; // spectral Pearson form: rows of the [2 M1][M2] sample matrix per band (what one lane group of k_fwd_cols_r
+                           // loads: asx_rlayout_band_rows), bands of the source = 2 M1 / band_rows; 0 = not available
     int rlayout;           // 1: this plan runs the real-column kernels (rlayout.hip); 0: the packed-sample kernels (xcorr_kernels.hip)
     const int4 *col_pairs; // real-column kernels (rlayout.hip): [M1/2 + 1] {u, slot of u, slot of M1 - u, 0}; null = not available
     const float2 *col_tw;  // w_{2 M1}^u, same order
@@ -120,6 +122,25 @@ struct AsxPeakWs {
     const double *shift;   // [pairs] or null: c with r[k] = (what the transforms deliver) + c for every k -- the second look at a pair
                            // runs the transforms on (source - mean), see second_look (asx_api.hip); null / 0 everywhere else
     uint32_t cap;          // candidate capacity per pair
+    // spectral Pearson (pearson_spectral.hip), both null when the plan does not use it:
+    float2 *band;          // [pairs][2][ntiles][nbands] {sum, sum of squares} of the samples of band x tile a k_fwd_cols_r block loaded
+                           // (band = AsxDev::band_rows consecutive rows of the [2 M1][M2] sample matrix; the sample fills the first half)
+    float *tile_peak;      // [pairs][M2 / T] SIGNED float32 r (times F) at the best lag of each k_inv_cols_r tile
+};
+
+// Spectral Pearson: the coefficient from r[peak] and window sums instead of a second pass over the inputs.
+// Modes a pair can take (k_pearson_prep decides, k_pearson_partial / k_pearson_final_spec act on it):
+#define ASX_PM_FAST 0    // lag >= 0: cross term = r[peak], window sums from the band sums + two band edges; nothing else is read
+#define ASX_PM_CORR 1    // lag < 0:  cross term = r[peak] - (wrap-around part, |lag| products, exact), sums as above
+#define ASX_PM_DIRECT 2  // the reference's own reduction over the segment (src/cross_correlation.c:74-116): the error bound of the
+                         // spectral form is not below the tolerance, or the segment is shorter than the wrap-around part
+#define ASX_PM_NMODES 3
+#define ASX_PRE_DOUBLES 8 // n, Sx, Sxx, Sy, Syy, r (plain sum scale), mode, bound
+struct AsxSpecWs {
+    AsxSeg *seg2;          // [pairs] what k_pearson_partial walks: nothing, the wrap-around part, or the segment itself
+    double *pre;           // [pairs][ASX_PRE_DOUBLES]
+    unsigned long long *mode_count; // [ASX_PM_NMODES] cumulative
+    double tol;            // a pair leaves the spectral form when its error bound exceeds this (1e-5: north_star's tolerance)
 };
 
 void asx_launch_fwd_cols(const AsxDev &P, const float *src, const float *smp, float2 *zxa,
@@ -135,6 +156,7 @@ bool asx_launch_fwd_cols_r(const AsxDev &P, const float *src, const float *smp, 
                            int npairs, hipStream_t s);
 bool asx_launch_inv_cols_r(const AsxDev &P, const float2 *q, const AsxPeakWs &W, float *r_out, int npairs, hipStream_t s);
 bool asx_rlayout_available(const AsxDev &P); // all three kernels compiled in for this plan's schedules
+int asx_rlayout_band_rows(const AsxDev &P);
 void asx_launch_finalize(const AsxDev &P, const AsxPeakWs &W, AsxSeg *seg, int npairs, hipStream_t s, uint32_t pair_base = 0);
 void asx_launch_refine_f32(const AsxDev &P, const float *src, const float *smp, const AsxPeakWs &W,
                            AsxSeg *seg, int npairs, hipStream_t s, int dot_blocks = ASX_DOT_BLOCKS);
@@ -146,6 +168,13 @@ void asx_launch_pearson_f32(const float *src, const float *smp, size_t src_pitch
 void asx_launch_pearson_f64(const double *src, const double *smp, size_t src_pitch, size_t smp_pitch,
                             uint32_t basis_len, const AsxSeg *seg, double *psums, int64_t *lag,
                             double *coef, int32_t *ret, int npairs, hipStream_t s);
+// the partial-sum kernel alone (the spectral form runs it on its own segment list, pearson_spectral.hip)
+void asx_launch_pearson_partial_f32(const float *src, const float *smp, size_t src_pitch, size_t smp_pitch,
+                                    uint32_t basis_len, const AsxSeg *seg, double *psums, int npairs, hipStream_t s);
+// pearson_spectral.hip: float32 inputs, real-column plans (W.band and W.tile_peak filled by this group's transform kernels)
+void asx_launch_pearson_spectral_f32(const AsxDev &P, const float *src, const float *smp, const AsxPeakWs &W, const AsxSpecWs &S,
+                                     const AsxSeg *seg, double *psums, int64_t *lag, double *coef, int32_t *ret, int npairs,
+                                     hipStream_t s);
 void asx_launch_results_to_ms(const int64_t *lag, const double *coef, const int32_t *ret, size_t batch,
                               double min_confidence, double sample_rate, int64_t *lag_ms, int32_t *accept,
                               hipStream_t s);

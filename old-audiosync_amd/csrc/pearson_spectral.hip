@@ -1,0 +1,221 @@
+// csrc/pearson_spectral.hip -- the Pearson coefficient (src/cross_correlation.c:74-116) WITHOUT a second pass over the inputs.
+//
+// The reference reads both segments twice (means, then centred sums).  Everything those sums are made of has already
+// passed through this path's kernels by the time the lag is known:
+//
+//   coefficient = (Sxy - Sx Sy / n) / sqrt((Sxx - Sx^2 / n) (Syy - Sy^2 / n))         (the same formula, expanded)
+//
+//   lag >= 0   source[lag .. lag + N) against sample[0 .. N)   (:264-271)
+//              Sxy = r[peak] EXACTLY the sum the transforms computed (no wrap-around: lag + N <= 2N);
+//   lag <  0   source[0 .. L) against sample[N - L .. N), L = N + lag   (:256-263)
+//              Sxy = r[peak] - sum_{n < -lag} source[peak + n] sample[n]   (the part of the circular sum that did not wrap):
+//              |lag| products instead of L, worth it when |lag| < L;
+//   Sx, Sxx, Sy, Syy   window sums: k_fwd_cols_r leaves {sum, sum of squares} of every (band of AsxDev::band_rows rows) x (tile)
+//              of the [2 M1][M2] sample matrix (AsxPeakWs::band) from the loads it makes anyway; a window is whole bands (their
+//              cells summed here, <= 144 KB per track) plus two band edges (at most 2 * band_rows * M2 samples, read here).
+//
+// r[peak] is the float32 transforms' value (k_inv_cols_r leaves the SIGNED value of each tile's best lag, AsxPeakWs::tile_peak),
+// or the exact one when the pair's near-ties were re-evaluated (k_refine_dots).  Its error is bounded by the SAME bound B that
+// guards the lag (asx_internal.h); the band sums are float32 sums of 128 terms (a tree: relative error <= 16 eps).  k_pearson_prep
+// turns both into a bound on the coefficient's error and keeps the spectral form only when that bound is below `tol` (1e-5,
+// north_star's tolerance); otherwise -- quiet windows of a loud track, offsets, short segments -- the pair takes the reference's
+// own reduction (k_pearson_partial over the segment, ASX_PM_DIRECT).  Float32 inputs on real-column plans only; the double ABI,
+// the second look and the packed-sample kernels keep the direct reduction.
+//
+// Per pair the pass reads: FAST <= 2 band edges of each track (<= 0.3 MB at N = 1 440 000 instead of 11.5 MB); CORR + 8 |lag|
+// bytes; DIRECT 8 L bytes as before.
+#include "asx_internal.h"
+#include "xcorr_dev.h"
+
+#define ASX_PREP_THREADS 1024
+
+namespace {
+
+struct Acc2 {
+    double s1, s2;
+};
+
+// block-wide sum of (s1, s2), fixed order (lane tree, then waves in order); valid in every thread
+__device__ __forceinline__ Acc2 block_sum2(Acc2 v, double (*red)[ASX_PREP_THREADS / 64])
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        v.s1 += __shfl_xor(v.s1, off, 64);
+        v.s2 += __shfl_xor(v.s2, off, 64);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads(); // the previous use of `red`
+    if (lane == 0) { red[0][wave] = v.s1; red[1][wave] = v.s2; }
+    __syncthreads();
+    Acc2 t{ red[0][0], red[1][0] };
+    for (int w = 1; w < ASX_PREP_THREADS / 64; w++) { t.s1 += red[0][w]; t.s2 += red[1][w]; }
+    return t;
+}
+
+__device__ __forceinline__ void acc1(Acc2 &a, float f)
+{
+    const double v = (double)f;
+    a.s1 += v;
+    a.s2 = fma(v, v, a.s2);
+}
+
+// sum and sum of squares of track[lo .. hi) (float64 from the float32 samples), this thread's share: 16-byte loads over the
+// aligned middle (the track starts on a 16-byte boundary: 2N and N are multiples of four), the ragged ends by single lanes
+__device__ __forceinline__ void direct_range(const float *__restrict__ x, uint32_t lo, uint32_t hi, Acc2 &a)
+{
+    if (lo >= hi) return;
+    const uint32_t lo4 = (lo + 3u) & ~3u, hi4 = hi & ~3u;
+    if (lo4 >= hi4) { // no aligned quad inside
+        for (uint32_t i = lo + threadIdx.x; i < hi; i += ASX_PREP_THREADS) acc1(a, x[i]);
+        return;
+    }
+    if (threadIdx.x < lo4 - lo) acc1(a, x[lo + threadIdx.x]);
+    if (threadIdx.x < hi - hi4) acc1(a, x[hi4 + threadIdx.x]);
+    const float4 *q = reinterpret_cast<const float4 *>(x);
+    for (uint32_t i = (lo4 >> 2) + threadIdx.x; i < (hi4 >> 2); i += ASX_PREP_THREADS) {
+        const float4 v = q[i];
+        acc1(a, v.x); acc1(a, v.y); acc1(a, v.z); acc1(a, v.w);
+    }
+}
+
+// Window sums of one track over [lo, hi): whole bands from the band sums, the two edges from the samples.
+//   band: [ntiles][nbands] {sum, sum of squares} as k_fwd_cols_r left them (every block its own run); a band = gs consecutive samples.
+//   The (tile, band) cells of the window are dealt to the threads in order -- consecutive lanes walk the bands of a tile --
+//   and added in float64: a fixed order.
+__device__ __forceinline__ Acc2 window_sums(const float *__restrict__ x, const float2 *__restrict__ band, uint32_t gs, int ntiles,
+                                            int nbands, uint32_t lo, uint32_t hi, double (*red)[ASX_PREP_THREADS / 64])
+{
+    Acc2 a{ 0.0, 0.0 };
+    const uint32_t ba = (lo + gs - 1) / gs, bb = hi / gs;
+    if (ba < bb) {
+        direct_range(x, lo, ba * gs, a);
+        direct_range(x, bb * gs, hi, a);
+        const uint32_t w = bb - ba, cells = w * (uint32_t)ntiles;
+        const uint32_t dq = ASX_PREP_THREADS / w, dr = ASX_PREP_THREADS - dq * w; // one step of the cell index, as (tiles, bands)
+        uint32_t t = threadIdx.x / w, b = threadIdx.x - t * w;
+        for (uint32_t i = threadIdx.x; i < cells; i += ASX_PREP_THREADS) {
+            const float2 v = band[(size_t)t * nbands + ba + b];
+            a.s1 += (double)v.x;
+            a.s2 += (double)v.y;
+            t += dq; b += dr;
+            if (b >= w) { b -= w; t++; }
+        }
+    } else {
+        direct_range(x, lo, hi, a);
+    }
+    return block_sum2(a, red);
+}
+
+} // namespace
+
+// grid (npairs), ASX_PREP_THREADS.  Decides each pair's mode, leaves its window sums and r[peak] in pre[], its work list in seg2[].
+__global__ __launch_bounds__(ASX_PREP_THREADS) void k_pearson_prep(const AsxDev *__restrict__ Pp, const float *__restrict__ src,
+                                                                    const float *__restrict__ smp, AsxPeakWs W, AsxSpecWs S,
+                                                                    const AsxSeg *__restrict__ seg)
+{
+    __shared__ double red[2][ASX_PREP_THREADS / 64];
+    __shared__ double s_exact;
+    __shared__ int s_have_exact;
+    const size_t pair = blockIdx.x;
+    const uint32_t N = Pp->N;
+    const int M2 = Pp->M2, nbands = Pp->nbands;
+    const uint32_t gs = (uint32_t)Pp->band_rows * (uint32_t)M2;
+    const AsxSeg s = seg[pair];
+    double *pre = S.pre + pair * ASX_PRE_DOUBLES;
+    const asx_peak_t best = W.pairmax[pair];
+    // the exact r[peak] when the pair's near-ties were re-evaluated (k_refine_dots / k_refine_pick): the entry of the winner
+    if (threadIdx.x == 0) s_have_exact = 0;
+    __syncthreads();
+    const uint32_t nref = W.refine_n[pair];
+    for (uint32_t i = threadIdx.x; i < nref; i += ASX_PREP_THREADS)
+        if (W.refine_idx[pair * (size_t)W.cap + i] == s.peak) { s_exact = W.refine_val[pair * (size_t)W.cap + i]; s_have_exact = 1; }
+    __syncthreads();
+    // A pair the transforms had nothing to say about (silent or NaN track: no maximum), an empty segment, or a lag that is still
+    // the float32 placeholder of an overflowed list (the second look redoes it): the direct reduction, whatever it yields.
+    const bool direct = best == 0 || s.len == 0 || (s.flags & ASX_SEG_INEXACT) != 0;
+    double n = (double)s.len, Sx = 0, Sxx = 0, Sy = 0, Syy = 0, r = 0, bound = INFINITY;
+    int mode = ASX_PM_DIRECT;
+    if (!direct) { // block-uniform
+        const float *x = src + pair * (size_t)(2u * N), *y = smp + pair * (size_t)N;
+        const int ntiles = Pp->ntiles;
+        const float2 *bx = W.band + (size_t)pair * 2 * ntiles * nbands, *by = bx + (size_t)ntiles * nbands;
+        const Acc2 ax = window_sums(x, bx, gs, ntiles, nbands, s.src_off, s.src_off + s.len, red);
+        const Acc2 ay = window_sums(y, by, gs, ntiles, nbands, s.smp_off, s.smp_off + s.len, red);
+        Sx = ax.s1; Sxx = ax.s2; Sy = ay.s1; Syy = ay.s2;
+        // r[peak] in the plain-sum scale and the bound on its error
+        double rb;
+        if (s_have_exact) { r = s_exact; rb = 0.0; }
+        else {
+            const int T = Pp->T;
+            r = (double)W.tile_peak[pair * (size_t)(M2 / T) + (s.peak % (uint32_t)M2) / (uint32_t)T] / (double)Pp->F;
+            rb = 0.5 * (double)W.bound2[pair] / (double)Pp->F; // bound2 = 2B in the device's scale (F times the plain sum)
+        }
+        const double A = Sxx - Sx * Sx / n, B = Syy - Sy * Sy / n;
+        if (A > 0.0 && B > 0.0) {
+            // float32 band sums: <= 16 eps relative on a sum of squares, <= 16 eps * sum|x| <= 16 eps sqrt(n Sxx) on a plain sum
+            const double es = 16.0 * 5.9604645e-8;
+            const double dSx = es * sqrt(n * Sxx), dSy = es * sqrt(n * Syy);
+            const double dC = rb + (fabs(Sy) * dSx + fabs(Sx) * dSy) / n;
+            const double dA = es * Sxx + 2.0 * fabs(Sx) / n * dSx, dB = es * Syy + 2.0 * fabs(Sy) / n * dSy;
+            bound = dC / sqrt(A * B) + 0.5 * (dA / A + dB / B); // |coefficient| <= 1
+            if (bound <= S.tol) {
+                if (s.peak < N) mode = ASX_PM_FAST;
+                else if (N - s.len < s.len) mode = ASX_PM_CORR; // |lag| products instead of L
+            }
+        }
+    }
+    if (threadIdx.x == 0) {
+        AsxSeg w = s;
+        if (mode == ASX_PM_FAST) w.len = 0;
+        else if (mode == ASX_PM_CORR) { w.src_off = s.peak; w.smp_off = 0; w.len = N - s.len; }
+        S.seg2[pair] = w;
+        pre[0] = n; pre[1] = Sx; pre[2] = Sxx; pre[3] = Sy; pre[4] = Syy; pre[5] = r; pre[6] = (double)mode; pre[7] = bound;
+        atomicAdd(S.mode_count + mode, 1ull);
+    }
+}
+
+// grid (npairs), one wave per pair: k_pearson_final (xcorr_kernels.hip) with the two spectral modes in front of it.
+__global__ __launch_bounds__(64) void k_pearson_final_spec(const AsxSeg *__restrict__ seg, const double *__restrict__ psums, uint32_t nb,
+                                                            const double *__restrict__ pre_all, int64_t *__restrict__ lag,
+                                                            double *__restrict__ coef, int32_t *__restrict__ ret)
+{
+    const size_t pair = blockIdx.x;
+    const double *pre = pre_all + pair * ASX_PRE_DOUBLES;
+    const int mode = (int)pre[6];
+    PStat v;
+    v.n = v.mx = v.my = v.mxx = v.myy = v.cxy = 0.0;
+    if (mode != ASX_PM_FAST) { // wave-uniform
+        for (uint32_t b = threadIdx.x; b < nb; b += 64u) {
+            const double *p = psums + (pair * nb + b) * 6;
+            PStat o;
+            o.n = p[0];
+            if (o.n != 0.0) { o.mx = p[1]; o.my = p[2]; o.mxx = p[3]; o.myy = p[4]; o.cxy = p[5]; v = pstat_merge(v, o); }
+        }
+        v = pstat_wave_merge(v);
+    }
+    if (threadIdx.x == 0) {
+        const AsxSeg s = seg[pair];
+        double c;
+        if (mode == ASX_PM_DIRECT) {
+            c = v.cxy / sqrt(v.mxx * v.myy); // src/cross_correlation.c:115
+        } else {
+            const double n = pre[0], Sx = pre[1], Sxx = pre[2], Sy = pre[3], Syy = pre[4];
+            double sxy = pre[5];
+            if (mode == ASX_PM_CORR) sxy -= v.cxy + v.n * v.mx * v.my; // minus the products that did not wrap around
+            c = (sxy - Sx * Sy / n) / sqrt((Sxx - Sx * Sx / n) * (Syy - Sy * Sy / n));
+            c = c > 1.0 ? 1.0 : c < -1.0 ? -1.0 : c; // the reference's value cannot leave [-1, 1]; NaN stays NaN
+        }
+        if (lag) lag[pair] = s.lag;
+        coef[pair] = c;
+        if (ret) ret[pair] = (s.flags & ASX_SEG_INEXACT) ? 1 : (c != c) ? -1 : 0; // as k_pearson_final (:276)
+    }
+}
+
+void asx_launch_pearson_spectral_f32(const AsxDev &P, const float *src, const float *smp, const AsxPeakWs &W, const AsxSpecWs &S,
+                                     const AsxSeg *seg, double *psums, int64_t *lag, double *coef, int32_t *ret, int npairs,
+                                     hipStream_t s)
+{
+    hipLaunchKernelGGL(k_pearson_prep, dim3(npairs), dim3(ASX_PREP_THREADS), 0, s, P.self_dev, src, smp, W, S, seg);
+    asx_launch_pearson_partial_f32(src, smp, 2 * (size_t)P.N, P.N, P.N, S.seg2, psums, npairs, s);
+    hipLaunchKernelGGL(k_pearson_final_spec, dim3(npairs), dim3(64), 0, s, seg, psums, asx_pearson_blocks(P.N), S.pre, lag, coef, ret);
+}

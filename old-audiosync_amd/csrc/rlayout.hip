@@ -57,7 +57,7 @@ extern __shared__ __attribute__((aligned(16))) float2 asx_lds_r[];
 struct RArgs {
     const float2 *tw1, *tw2, *tw_lo, *tw_hi;
     uint32_t N, nout;
-    int M2, ntiles;
+    int M1, M2, ntiles;
     float bound_scale;
     unsigned long long *stamps;
     int stamp_kernel;
@@ -66,7 +66,7 @@ static RArgs rargs_of(const AsxDev &P)
 {
     RArgs a;
     a.tw1 = P.tw1; a.tw2 = P.tw2; a.tw_lo = P.tw_lo; a.tw_hi = P.tw_hi;
-    a.N = P.N; a.nout = P.nout; a.M2 = P.M2; a.ntiles = P.ntiles; a.bound_scale = P.bound_scale;
+    a.N = P.N; a.nout = P.nout; a.M1 = P.M1; a.M2 = P.M2; a.ntiles = P.ntiles; a.bound_scale = P.bound_scale;
     a.stamps = P.stamps; a.stamp_kernel = P.stamp_kernel;
     return a;
 }
@@ -102,6 +102,16 @@ __device__ __forceinline__ void wave_lds_sync()
 //                           of a launch whose intermediates never leave the 256 MiB Infinity Cache (upper bound of keeping
 //                           them on die, EXPERIMENTS.md)
 //   -DASX_ROWS2_SCHED=a,b,c the radix schedule of the 1200-point sub-rows of the two-half row kernel
+// sum over the four lanes of a quad (every lane gets it): two DPP steps
+__device__ __forceinline__ float quad_sum(float v)
+{
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true)); // quad_perm [1,0,3,2]
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true)); // quad_perm [2,3,0,1]
+    return v;
+}
+// row pairs a lane group of k_fwd_cols_r<Sched<m1, ...>, t, nt> loads = half the rows of a band (asx_rlayout_band_rows)
+__host__ __device__ constexpr int rcol_rows_per_group(int m1, int nt, int t) { return (m1 + nt / (t / 4) - 1) / (nt / (t / 4)); }
+
 #ifdef ASX_EXP_PAIRMOD
 #define RWS_PAIR(pair) ((pair) % (ASX_EXP_PAIRMOD))
 #else
@@ -386,7 +396,8 @@ static inline unsigned rcol_grid_x(int ntiles, int logT)
 template <class S1, int TC, int NT>
 __global__ __launch_bounds__(NT, 4) void k_fwd_cols_r(const RArgs P, const float *__restrict__ src,
                                                        const float *__restrict__ smp, float2 *__restrict__ cx,
-                                                       float2 *__restrict__ cy, float *__restrict__ nrm_part, size_t pair_pitch)
+                                                       float2 *__restrict__ cy, float *__restrict__ nrm_part, size_t pair_pitch,
+                                                       float2 *__restrict__ band)
 {
     constexpr int M1 = S1::n, T = TC, logT = asx_ilog2(TC), H = T / 2, logH = logT - 1, Q4 = T / 4, logQ4 = logT - 2;
     static_assert(T >= 4 && (M1 & 1) == 0, "four real columns per 16-byte load, an even number of packed rows");
@@ -404,14 +415,22 @@ __global__ __launch_bounds__(NT, 4) void k_fwd_cols_r(const RArgs P, const float
     const LdsLayout Lc = col_layout(T, logT, NT);
     const TwPre pre = tw_prefetch_first<S1, false, true>(Lc, P.tw1);
 
-    // work item e = (m, h): rows 2m and 2m+1, real columns c0 + 4h .. 4h+3 -> slots (m, 2h) and (m, 2h+1)
-    constexpr int NITEMS = M1 * Q4;
-    float ss = 0.f;
-    for (int e0 = threadIdx.x; e0 < NITEMS; e0 += ASX_RCOL_LOADS * NT) {
-        float4 a[ASX_RCOL_LOADS], b[ASX_RCOL_LOADS];
-        static_for<0, ASX_RCOL_LOADS>([&](auto I) __attribute__((always_inline)) {
-            const int e = e0 + decltype(I)::value * NT;
-            const int h = e & (Q4 - 1), m = e >> logQ4;
+    // Work items (m, h): rows 2m and 2m+1, real columns c0 + 4h .. 4h+3 -> slots (m, 2h) and (m, 2h+1).  The Q4 lanes h of a lane
+    // group take RPQ CONSECUTIVE row pairs m = RPQ * group + i (each a 64-byte piece of two rows: the addresses a wave asks for
+    // are 16 pieces apart whichever way the pairs are dealt).  That makes a lane group the owner of one BAND of 2 RPQ rows x T
+    // columns, whose sum and sum of squares -- what the spectral Pearson form (pearson_spectral.hip) builds its window sums
+    // from -- are RPQ register additions and two DPP steps away from the loads this pass makes anyway.  (Dealing the pairs
+    // round-robin, 16 lanes of a wave per band of eight rows: five 16-lane reductions per thread, k_fwd_cols_r +3 %,
+    // profiles/r5_experiments/04_*.)
+    constexpr int QN = NT / Q4, RPQ = rcol_rows_per_group(M1, NT, T);
+    static_assert(Q4 == 4, "sixteen real columns: four lanes per row pair (the quad reductions below)");
+    static_assert(M1 % RPQ == 0 && (M1 / 2) % RPQ == 0 && RPQ <= ASX_RCOL_LOADS && RPQ * QN >= M1, "whole bands in both tracks");
+    const int grp = threadIdx.x >> logQ4, h = threadIdx.x & (Q4 - 1), m0 = grp * RPQ;
+    float ss = 0.f, q1 = 0.f;
+    {
+        float4 a[RPQ], b[RPQ];
+        static_for<0, RPQ>([&](auto I) __attribute__((always_inline)) {
+            const int m = m0 + decltype(I)::value;
             a[I] = b[I] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (m < data_m) { // also false past the end of the tile (m >= M1 >= data_m)
                 const float *p = in + (size_t)(2 * m) * M2 + c0 + 4 * h;
@@ -419,17 +438,25 @@ __global__ __launch_bounds__(NT, 4) void k_fwd_cols_r(const RArgs P, const float
                 b[I] = *reinterpret_cast<const float4 *>(p + M2);
             }
         });
-        static_for<0, ASX_RCOL_LOADS>([&](auto I) __attribute__((always_inline)) {
-            const int e = e0 + decltype(I)::value * NT;
-            if (e < NITEMS) {
-                const int h = e & (Q4 - 1), m = e >> logQ4;
+        static_for<0, RPQ>([&](auto I) __attribute__((always_inline)) {
+            const int m = m0 + decltype(I)::value;
+            if (m < M1) {
                 float4 *o = lds4 + (m << logH) + 2 * h;
                 o[0] = make_float4(a[I].x, b[I].x, a[I].y, b[I].y);
                 o[1] = make_float4(a[I].z, b[I].z, a[I].w, b[I].w);
-                ss = fmaf(a[I].x, a[I].x, fmaf(a[I].y, a[I].y, fmaf(a[I].z, a[I].z, fmaf(a[I].w, a[I].w, ss))));
-                ss = fmaf(b[I].x, b[I].x, fmaf(b[I].y, b[I].y, fmaf(b[I].z, b[I].z, fmaf(b[I].w, b[I].w, ss))));
             }
+            // (row pairs past the end of the tile or in the sample's zero half hold zeros)
+            ss = fmaf(a[I].x, a[I].x, fmaf(a[I].y, a[I].y, fmaf(a[I].z, a[I].z, fmaf(a[I].w, a[I].w, ss))));
+            ss = fmaf(b[I].x, b[I].x, fmaf(b[I].y, b[I].y, fmaf(b[I].z, b[I].z, fmaf(b[I].w, b[I].w, ss))));
+            if (band) q1 += ((a[I].x + a[I].y) + (a[I].z + a[I].w)) + ((b[I].x + b[I].y) + (b[I].z + b[I].w)); // kernel-uniform
         });
+    }
+    if (band) {
+        const float r1 = quad_sum(q1), r2 = quad_sum(ss);
+        // tile-major: a block's band sums are one contiguous run (row-major -- adjacent tiles 8 bytes apart, sixteen blocks of
+        // eight XCDs writing into every 128-byte line: k_fwd_cols_r +2 % at 600 x 2400, +7 % at 400 x 1200, profiles/r5_experiments/04_*)
+        if (h == 0 && m0 < data_m)
+            band[(((size_t)pair * 2 + which) * (size_t)P.ntiles + tile) * (size_t)(M1 / RPQ) + grp] = make_float2(r1, r2);
     }
     // |source|^2 and |sample|^2 (the scale of the float32 error bound of the peak search) from the pass that reads
     // the inputs anyway
@@ -686,6 +713,11 @@ __global__ __launch_bounds__(NT, 4) void k_inv_cols_r(const RArgs P, const float
         asx_peak_t tb = red[0];
         for (int w = 1; w < NT / 64; w++) tb = peak_max(tb, red[w]);
         if (threadIdx.x == 0) atomicMax(&W.pairmax[pair], tb);
+        if (W.tile_peak && best_m == wmax && my_idx == widx && tb == peak_pack_key(wmax, widx)) {
+            // the one lane that holds the tile's best lag: its SIGNED value (the key is |r|) for the spectral Pearson form
+            const float sv = fabsf(gb.x) == best_m ? gb.x : fabsf(gb.z) == best_m ? gb.z : fabsf(gb.y) == best_m ? gb.y : gb.w;
+            W.tile_peak[pair * (size_t)(P.M2 / T) + tile] = sv;
+        }
         RSTAMP(2, sblock, 5);
         const float thr = near_max_threshold(peak_key(peak_max(tb, run0)), b2);
         thr_again = thr;
@@ -701,7 +733,7 @@ __global__ __launch_bounds__(NT, 4) void k_inv_cols_r(const RArgs P, const float
         }
     } else {
         // general form: first tile (lag 0 competes signed), r dumped for tests, shifted keys of the second look
-        float best_key = -INFINITY;
+        float best_key = -INFINITY, best_val = 0.f;
         uint32_t best_idx = 0xFFFFFFFFu;
         last_stage([&](auto RC, auto &v, int g, int pos0, int q) __attribute__((always_inline)) {
             static_for<0, decltype(RC)::value>([&](auto TT) __attribute__((always_inline)) {
@@ -712,15 +744,16 @@ __global__ __launch_bounds__(NT, 4) void k_inv_cols_r(const RArgs P, const float
                 for (int h = 0; h < 4; h++) {
                     const uint32_t idx = i0 + (uint32_t)(h & 1) * uM2 + (uint32_t)(h >> 1);
                     const float key = shift == 0.0 ? peak_key_of(val[h], idx) : peak_key_shifted(val[h], idx, shift);
-                    if (key > best_key || (key == best_key && idx < best_idx) || best_idx == 0xFFFFFFFFu) { best_key = key; best_idx = idx; }
+                    if (key > best_key || (key == best_key && idx < best_idx) || best_idx == 0xFFFFFFFFu) { best_key = key; best_idx = idx; best_val = val[h]; }
                     if (r_out) r_out[pair * (size_t)P.nout + idx] = val[h];
                 }
             });
         });
-        asx_peak_t best = best_idx == 0xFFFFFFFFu ? 0 : peak_pack_key(best_key, best_idx);
-        best = block_peak_max(best, red);
+        const asx_peak_t mine = best_idx == 0xFFFFFFFFu ? 0 : peak_pack_key(best_key, best_idx);
+        asx_peak_t best = block_peak_max(mine, red);
         if (threadIdx.x == 0) { atomicMax(&W.pairmax[pair], best); red[0] = best; }
         __syncthreads();
+        if (W.tile_peak && mine != 0 && mine == red[0]) W.tile_peak[pair * (size_t)(P.M2 / T) + tile] = best_val; // one thread: indices are unique
         const float thr = near_max_threshold(peak_key(peak_max(red[0], run0)), b2);
         again = best_key >= thr;
         thr_again = thr;
@@ -787,7 +820,7 @@ bool asx_launch_fwd_cols_r(const AsxDev &P, const float *src, const float *smp, 
     if (P.T == (t) && schedule_is_r(P.st1, m1, { __VA_ARGS__ })) {                                    \
         allow_big_lds_r((const void *)k_fwd_cols_r<Sched<m1, __VA_ARGS__>, t, nt>, lds);                                    \
         hipLaunchKernelGGL((k_fwd_cols_r<Sched<m1, __VA_ARGS__>, t, nt>), grid, dim3(nt), lds, s, rargs_of(P), src, smp, cx, cy, \
-                           W.nrm_part, pitch);                                                                              \
+                           W.nrm_part, pitch, W.band);                                                                      \
         return true;                                                                                                        \
     }
     ASX_RCOLS(ASX_TRY)
@@ -810,6 +843,15 @@ bool asx_launch_inv_cols_r(const AsxDev &P, const float2 *q, const AsxPeakWs &W,
     ASX_RCOLS(ASX_TRY)
 #undef ASX_TRY
     return false;
+}
+
+// rows of the sample matrix per band of the spectral Pearson form = what one lane group of this plan's k_fwd_cols_r loads; 0 = no kernel
+int asx_rlayout_band_rows(const AsxDev &P)
+{
+#define ASX_TRY(m1, t, nt, ...) if (P.T == (t) && schedule_is_r(P.st1, m1, { __VA_ARGS__ })) return 2 * rcol_rows_per_group(m1, nt, t);
+    ASX_RCOLS(ASX_TRY)
+#undef ASX_TRY
+    return 0;
 }
 
 bool asx_rlayout_available(const AsxDev &P)

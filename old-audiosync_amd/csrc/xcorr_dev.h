@@ -203,3 +203,67 @@ __device__ __forceinline__ void cand_append(const AsxPeakWs &W, size_t pair, uin
     }
 }
 
+// ---------------------------------------------------------------------------
+// lag wrap + segments (src/cross_correlation.c:256-271)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ AsxSeg make_seg(uint32_t peak, uint32_t N)
+{
+    AsxSeg s;
+    s.peak = peak;
+    s.flags = 0;
+    if (peak >= N) {
+        // src/cross_correlation.c:256-263: lag = (lag % N) - N; source[0 .. N+lag), sample[-lag .. N)
+        const long long l = (long long)(peak % N) - (long long)N;
+        s.lag = l;
+        s.src_off = 0;
+        s.smp_off = (uint32_t)(-l);
+        s.len = (uint32_t)((long long)N + l);
+    } else {
+        // :264-271: source[lag .. lag+N), sample[0 .. N)
+        s.lag = (long long)peak;
+        s.src_off = peak;
+        s.smp_off = 0;
+        s.len = N;
+    }
+    return s;
+}
+
+// ---------------------------------------------------------------------------
+// Pearson partial statistics and their exact pairwise merge (Chan et al.); see k_pearson_partial
+// ---------------------------------------------------------------------------
+struct PStat {
+    double n, mx, my, mxx, myy, cxy;
+};
+__device__ __forceinline__ PStat pstat_merge(const PStat A, const PStat B)
+{
+    if (B.n == 0.0) return A;
+    if (A.n == 0.0) return B;
+    const double n = A.n + B.n;
+    const double dx = B.mx - A.mx, dy = B.my - A.my;
+    const double fb = B.n / n, w = A.n * fb;
+    PStat R;
+    R.n = n;
+    R.mx = A.mx + dx * fb;
+    R.my = A.my + dy * fb;
+    R.mxx = (A.mxx + B.mxx) + (dx * dx) * w;
+    R.myy = (A.myy + B.myy) + (dy * dy) * w;
+    R.cxy = (A.cxy + B.cxy) + (dx * dy) * w;
+    return R;
+}
+__device__ __forceinline__ PStat pstat_wave_merge(PStat v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        PStat o;
+        o.n = __shfl_xor(v.n, off, 64);
+        o.mx = __shfl_xor(v.mx, off, 64);
+        o.my = __shfl_xor(v.my, off, 64);
+        o.mxx = __shfl_xor(v.mxx, off, 64);
+        o.myy = __shfl_xor(v.myy, off, 64);
+        o.cxy = __shfl_xor(v.cxy, off, 64);
+        // the lane with the lower index is always "A": both partners then compute the same merge
+        const bool lower = (threadIdx.x & off) == 0;
+        v = lower ? pstat_merge(v, o) : pstat_merge(o, v);
+    }
+    return v;
+}

@@ -864,28 +864,6 @@ __global__ __launch_bounds__(ASX_FFT_THREADS_MAX, 4) void k_inv_cols(const AsxDe
 // ---------------------------------------------------------------------------
 // k_finalize: grid (npairs).  Reduce tile partials, wrap the lag, pick segments.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ AsxSeg make_seg(uint32_t peak, uint32_t N)
-{
-    AsxSeg s;
-    s.peak = peak;
-    s.flags = 0;
-    if (peak >= N) {
-        // src/cross_correlation.c:256-263: lag = (lag % N) - N; source[0 .. N+lag), sample[-lag .. N)
-        const long long l = (long long)(peak % N) - (long long)N;
-        s.lag = l;
-        s.src_off = 0;
-        s.smp_off = (uint32_t)(-l);
-        s.len = (uint32_t)((long long)N + l);
-    } else {
-        // :264-271: source[lag .. lag+N), sample[0 .. N)
-        s.lag = (long long)peak;
-        s.src_off = peak;
-        s.smp_off = 0;
-        s.len = N;
-    }
-    return s;
-}
-
 __global__ __launch_bounds__(ASX_THREADS) void k_finalize(const AsxDev *__restrict__ Pp, AsxPeakWs W, AsxSeg *__restrict__ seg,
                                                            uint32_t pair_base)
 {
@@ -1047,43 +1025,7 @@ __global__ __launch_bounds__(ASX_THREADS) void k_refine_pick(const AsxDev *__res
 // The merge tree is fixed, and x and y go through the same operations, so identical segments give
 // bit-identical Mxx, Myy, Cxy and therefore exactly +-1.0 (tests/test_cross_correlation.c:29).
 // ---------------------------------------------------------------------------
-struct PStat {
-    double n, mx, my, mxx, myy, cxy;
-};
-__device__ __forceinline__ PStat pstat_merge(const PStat A, const PStat B)
-{
-    if (B.n == 0.0) return A;
-    if (A.n == 0.0) return B;
-    const double n = A.n + B.n;
-    const double dx = B.mx - A.mx, dy = B.my - A.my;
-    const double fb = B.n / n, w = A.n * fb;
-    PStat R;
-    R.n = n;
-    R.mx = A.mx + dx * fb;
-    R.my = A.my + dy * fb;
-    R.mxx = (A.mxx + B.mxx) + (dx * dx) * w;
-    R.myy = (A.myy + B.myy) + (dy * dy) * w;
-    R.cxy = (A.cxy + B.cxy) + (dx * dy) * w;
-    return R;
-}
-__device__ __forceinline__ PStat pstat_wave_merge(PStat v)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        PStat o;
-        o.n = __shfl_xor(v.n, off, 64);
-        o.mx = __shfl_xor(v.mx, off, 64);
-        o.my = __shfl_xor(v.my, off, 64);
-        o.mxx = __shfl_xor(v.mxx, off, 64);
-        o.myy = __shfl_xor(v.myy, off, 64);
-        o.cxy = __shfl_xor(v.cxy, off, 64);
-        // the lane with the lower index is always "A": both partners then compute the same merge
-        const bool lower = (threadIdx.x & off) == 0;
-        v = lower ? pstat_merge(v, o) : pstat_merge(o, v);
-    }
-    return v;
-}
-
+// (PStat, pstat_merge, pstat_wave_merge: xcorr_dev.h -- shared with pearson_spectral.hip)
 template <typename TIn>
 __global__ __launch_bounds__(ASX_THREADS) void k_pearson_partial(const TIn *__restrict__ src,
                                                                   const TIn *__restrict__ smp,
@@ -1101,6 +1043,12 @@ __global__ __launch_bounds__(ASX_THREADS) void k_pearson_partial(const TIn *__re
     const uint64_t lo = (uint64_t)blockIdx.x * chunk;
     uint64_t hi = lo + chunk;
     if (hi > s.len) hi = s.len;
+    if (lo >= s.len) {
+        // nothing of the segment falls to this block (block-uniform): an empty record (pstat_merge skips n == 0) -- the whole
+        // launch for a pair the spectral form has settled (pearson_spectral.hip), the tail of a short segment otherwise
+        if (threadIdx.x == 0) psums[(pair * gridDim.x + blockIdx.x) * 6] = 0.0;
+        return;
+    }
     const TIn *x = src + pair * src_pitch + s.src_off;
     const TIn *y = smp + pair * smp_pitch + s.smp_off;
     uint64_t i = lo + 4u * threadIdx.x;
@@ -1564,6 +1512,14 @@ void asx_launch_pearson_f32(const float *src, const float *smp, size_t src_pitch
     hipLaunchKernelGGL(k_pearson_partial<float>, dim3(nb, npairs), dim3(ASX_THREADS), 0, s,
                        src, smp, src_pitch, smp_pitch, basis_len, seg, psums);
     hipLaunchKernelGGL(k_pearson_final, dim3(npairs), dim3(64), 0, s, seg, psums, nb, lag, coef, ret);
+}
+
+void asx_launch_pearson_partial_f32(const float *src, const float *smp, size_t src_pitch, size_t smp_pitch,
+                                    uint32_t basis_len, const AsxSeg *seg, double *psums, int npairs, hipStream_t s)
+{
+    const unsigned nb = asx_pearson_blocks(basis_len);
+    hipLaunchKernelGGL(k_pearson_partial<float>, dim3(nb, npairs), dim3(ASX_THREADS), 0, s,
+                       src, smp, src_pitch, smp_pitch, basis_len, seg, psums);
 }
 
 void asx_launch_pearson_f64(const double *src, const double *smp, size_t src_pitch, size_t smp_pitch,

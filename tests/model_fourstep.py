@@ -237,6 +237,57 @@ def reference_r(source, sample):
 
 
 # ---------------------------------------------------------------------------
+# Spectral form of the Pearson coefficient (csrc/pearson_spectral.hip), step by step in float64:
+#   window sums = whole bands of `band_rows` rows of the [rows][M2] sample matrix (per band x tile partial sums, as
+#   k_fwd_cols_r leaves them) + the two band edges;  cross term = r[peak], minus -- for a negative lag -- the products
+#   of the circular sum that did not wrap around.
+# ---------------------------------------------------------------------------
+def band_partials(x, M2, T, band_rows=8):
+    """[nbands][ntiles][2]: sum and sum of squares of every (band, tile) cell; len(x) is a multiple of band_rows * M2"""
+    x = np.asarray(x, dtype=float)
+    rows = len(x) // M2
+    m = x.reshape(rows // band_rows, band_rows, M2 // T, T)
+    return np.stack([m.sum(axis=(1, 3)), (m * m).sum(axis=(1, 3))], axis=-1)
+
+
+def window_sums(x, part, M2, lo, hi, band_rows=8):
+    """sum and sum of squares of x[lo:hi] from whole bands of `part` plus the two edges (the whole range if it holds no band)"""
+    gs = band_rows * M2
+    ba, bb = -(-lo // gs), hi // gs
+    x = np.asarray(x, dtype=float)
+    if ba < bb:
+        e = np.concatenate([x[lo: ba * gs], x[bb * gs: hi]])
+        return e.sum() + part[ba:bb, :, 0].sum(), (e * e).sum() + part[ba:bb, :, 1].sum()
+    e = x[lo:hi]
+    return e.sum(), (e * e).sum()
+
+
+def spectral_pearson(source, sample, peak, M2, T=16, band_rows=8):
+    """(lag, coefficient, mode) as k_pearson_prep / k_pearson_final_spec form them, with the exact r[peak] and no error gate"""
+    source = np.asarray(source, dtype=float); sample = np.asarray(sample, dtype=float)
+    N = len(sample)
+    r_peak = float(np.dot(np.roll(source, -peak)[:N], sample))      # the circular sum of src/cross_correlation.c:232-239
+    if peak >= N:   # src/cross_correlation.c:256-263
+        lag = (peak % N) - N
+        so, mo, L = 0, -lag, N + lag
+    else:           # :264-271
+        lag, so, mo, L = peak, peak, 0, N
+    px, py = band_partials(source, M2, T, band_rows), band_partials(sample, M2, T, band_rows)
+    Sx, Sxx = window_sums(source, px, M2, so, so + L, band_rows)
+    Sy, Syy = window_sums(sample, py, M2, mo, mo + L, band_rows)
+    mode = "fast"
+    sxy = r_peak
+    if peak >= N:
+        mode = "corr"
+        c = N - L                                                   # = -lag products source[peak + n] * sample[n] did not wrap
+        sxy -= float(np.dot(source[peak: peak + c], sample[:c]))
+    if L < 2:
+        return lag, float("nan"), mode
+    coef = (sxy - Sx * Sy / L) / np.sqrt((Sxx - Sx * Sx / L) * (Syy - Sy * Sy / L))
+    return lag, coef, mode
+
+
+# ---------------------------------------------------------------------------
 # In-place DIF / DIT stage model (what csrc/lds_fft.hip does inside LDS).
 #   forward : natural order in  -> digit-reversed out   (Gentleman-Sande, DIF)
 #   inverse : digit-reversed in -> natural order out    (Cooley-Tukey,   DIT)

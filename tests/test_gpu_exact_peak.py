@@ -420,15 +420,20 @@ def test_moderate_offsets_where_the_shift_is_comparable_to_r(mod):
 def test_float32_exact_doubles_cross_pcie_as_float32_and_give_the_same_bits(mod):
     """cross_correlation(double*) on frames that are exactly float32 (what ffmpeg decodes from 16-bit / float
     audio, src/capture/linux_capture.c:370) uploads 4 bytes per frame and runs the float64 passes on the widened copy: the
-    coefficient is bit-identical to the batched float32 entry point's (the same values through the same operations) and
-    within 1e-5 of the oracle; doubles that float32 cannot hold, and NaNs, keep the 8-byte route."""
+    coefficient is bit-identical to the batched float32 entry point's DIRECT Pearson form (the same values through the same
+    operations; the double ABI never takes the spectral form, include/audiosync/xcorr_hip.h) and within 1e-5 of the oracle and
+    of the spectral form; doubles that float32 cannot hold, and NaNs, keep the 8-byte route."""
     n = 144000
     src32, smp32, true_lag = oracle.synth_pair(55, 1, n, 1)
     s64, t64 = src32.astype(np.float64), smp32.astype(np.float64)
     with mod.Plan(n, 1, 0) as plan:
         ret, lag, coef = plan.xcorr_f64(s64, t64)
         assert plan.narrowed_calls() == 1
+        lag_s, coef_s, ret_s = plan.xcorr_batch_f32(src32[None], smp32[None])      # spectral form (the default here)
+        assert (ret, lag) == (int(ret_s[0]), int(lag_s[0])) == (0, true_lag) and abs(coef - float(coef_s[0])) < 1e-5
+        plan.set_pearson(False)
         lag_b, coef_b, ret_b = plan.xcorr_batch_f32(src32[None], smp32[None])
+        plan.set_pearson(True)
         assert (ret, lag) == (int(ret_b[0]), int(lag_b[0])) == (0, true_lag) and coef == float(coef_b[0])
         o_ret, o_lag, o_coef = oracle.cross_correlation(s64, t64)
         assert (ret, lag) == (o_ret, o_lag) and abs(coef - o_coef) < 1e-5

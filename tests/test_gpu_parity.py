@@ -723,6 +723,7 @@ def test_generic_kernels_agree_with_compiled_in_schedules(mod):
         env = dict(os.environ)
         env.pop("ASX_GENERIC", None)
         env.update(env_extra)
+        env["ASX_PEARSON"] = "direct"   # the comparison is about the transform kernels: both sides the direct Pearson form
         p = subprocess.run([sys.executable, "-c", _GENERIC_PROBE % {"root": root}], env=env, capture_output=True,
                            text=True, timeout=600)
         assert p.returncode == 0, p.stderr[-2000:]

@@ -122,3 +122,31 @@ def test_real_column_decomposition_matches_the_reference_recipe(m1, m2):
     r = model.rlayout_xcorr(src, smp, m1, m2)
     ref = model.reference_r(src, smp)
     assert np.abs(r - ref).max() < 1e-9 * np.abs(ref).max()
+
+
+def test_spectral_pearson_algebra_matches_the_reference_reduction():
+    """csrc/pearson_spectral.hip's identity, in float64: r[peak] (minus the products that did not wrap around, for a negative
+    lag) and band + edge window sums give pearson_coefficient() of the segments src/cross_correlation.c:256-271 selects --
+    for lags inside a band, on band borders, with windows that hold no whole band, and with offsets in both tracks."""
+    import oracle
+    M2, T, rows = 48, 16, 40                  # a [40][48] sample matrix for the sample, [80][48] for the source; bands of 8 rows
+    N = rows * M2
+    gs = 8 * M2
+    rng = np.random.default_rng(17)
+    source = rng.normal(size=2 * N) + 0.3
+    sample = rng.normal(size=N) - 0.2
+    peaks = [0, 1, 5, gs - 1, gs, gs + 1, 3 * gs, N - 1, N - gs, N, N + 1, N + 7, N + gs, 2 * N - gs, 2 * N - gs - 3, 2 * N - 5,
+             2 * N - 1, N + N // 2]
+    for peak in peaks:
+        lag, coef, mode = model.spectral_pearson(source, sample, peak, M2, T)
+        if peak >= N:
+            want_lag = (peak % N) - N
+            a, b = source[: N + want_lag], sample[-want_lag:]
+        else:
+            want_lag = peak
+            a, b = source[peak: peak + N], sample
+        assert lag == want_lag
+        if len(a) < 2:
+            continue
+        want = oracle.pearson_coefficient(a.copy(), b.copy())
+        assert abs(coef - want) < 1e-10, (peak, mode, coef, want)

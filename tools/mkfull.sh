@@ -14,10 +14,11 @@ for p in 1 2 4 8 16 32 64; do
   objs="$objs $D/k$p.o"
 done
 /opt/rocm/bin/hipcc $F $flags -c -o $D/rlayout.o $P/csrc/rlayout.hip &
+/opt/rocm/bin/hipcc $F $flags -c -o $D/pspec.o $P/csrc/pearson_spectral.hip &
 /opt/rocm/bin/hipcc $F $flags -c -o $D/api.o $P/csrc/asx_api.hip &
 /opt/rocm/bin/hipcc $F $flags -c -o $D/plan.o $P/csrc/plan_math.cpp &
 /opt/rocm/bin/hipcc $F $flags -c -o $D/shard.o $P/csrc/shard_driver.cpp &
 /opt/rocm/bin/hipcc $F $flags -c -o $D/narrow.o $P/csrc/host_narrow.cpp &
 wait
-/opt/rocm/bin/hipcc -fPIC --offload-arch=gfx950 -shared -o $R/ab/$name.so $D/api.o $D/plan.o $D/shard.o $D/narrow.o $D/rlayout.o $objs -ldl -lpthread
+/opt/rocm/bin/hipcc -fPIC --offload-arch=gfx950 -shared -o $R/ab/$name.so $D/api.o $D/plan.o $D/shard.o $D/narrow.o $D/rlayout.o $D/pspec.o $objs -ldl -lpthread
 echo "ab/$name.so"

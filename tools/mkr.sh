@@ -9,7 +9,7 @@ mkdir -p $R/ab /tmp/asx_r/$name
 F="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-finite-math-only -fno-slp-vectorize -Wall -Wno-unused-function -I$R/include -I$P/csrc"
 kf=""   # as in the Makefile (KFLAGS_RLAYOUT)
 /opt/rocm/bin/hipcc $F $kf $flags -c -o /tmp/asx_r/$name/rlayout.o $P/csrc/rlayout.hip
-objs="$P/build/asx_api.o $P/build/plan_math.o $P/build/shard_driver.o $P/build/host_narrow.o /tmp/asx_r/$name/rlayout.o"
+objs="$P/build/asx_api.o $P/build/plan_math.o $P/build/shard_driver.o $P/build/host_narrow.o $P/build/pearson_spectral.o /tmp/asx_r/$name/rlayout.o"
 for p in 1 2 4 8 16 32 64; do objs="$objs $P/build/kernels_$p.o"; done
 /opt/rocm/bin/hipcc -fPIC --offload-arch=gfx950 -shared -o $R/ab/$name.so $objs -ldl -lpthread
 echo "ab/$name.so"

@@ -7,7 +7,7 @@ R=$(cd "$(dirname "$0")/.." && pwd); P=$R/old-audiosync_amd
 name=$1; flags=$2; shift 2; parts=${@:-1 2 4 8 16 32 64}
 mkdir -p $R/ab /tmp/asx_var/$name
 F="${ASX_OPT:--O3} -std=c++17 -fPIC --offload-arch=${ASX_ARCH:-gfx950} -fno-finite-math-only -fno-slp-vectorize -Wall -Wno-unused-function -I$R/include -I$P/csrc"
-objs="$P/build/asx_api.o $P/build/plan_math.o $P/build/shard_driver.o $P/build/host_narrow.o $P/build/rlayout.o"
+objs="$P/build/asx_api.o $P/build/plan_math.o $P/build/shard_driver.o $P/build/host_narrow.o $P/build/rlayout.o $P/build/pearson_spectral.o"
 for p in 1 2 4 8 16 32 64; do
   if [[ " $parts " == *" $p "* ]]; then
     kf=""; case $p in 1|4|16) kf="-mllvm -amdgpu-sched-strategy=iterative-ilp";; esac   # as in the Makefile (KFLAGS_STATIC)
