@@ -556,7 +556,17 @@ __global__ __launch_bounds__(NT, 4) void k_inv_cols_r(const RArgs P, const float
     // at 300 rows (profiles/r5_experiments/02_*).
     const size_t pair = blockIdx.x;
     const int tile = rcol_tile_of_block(blockIdx.y, logT);
-    if (tile * T >= P.M2) return; // the tile count is rounded up; the tile width is this kernel's own (it reads only)
+    {
+        // Stagger: the blocks that share a CU run the same program -- a load phase (the tile's rows), then compute phases of about
+        // the same length -- and, started together, stay in step: both wait for memory, then both compute.  The blocks of the FIRST
+        // generation start a fraction of a block's life apart, by their position in the launch order (consecutive blocks land on
+        // the same CU more often than not); later generations inherit the offset.  0.370 -> 0.349 ms at 600 rows, -3 .. -6 % at 400 (rows and
+        // forward columns: nothing, profiles/r5_experiments/05_*).  Speed only.
+        constexpr bool TWO_PER_CU = (size_t)M1 * T * 8 > 40 * 1024; // 600- and 400-row tiles; four blocks of 300 rows: measured 1.5 % slower
+        const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y;
+        if (TWO_PER_CU && lin < 512u && (lin & 1u))
+            for (unsigned i = 0; i < (unsigned)(M1 * 27 / 64 / 2); i += 16) __builtin_amdgcn_s_sleep(16); // half a block's life; 64 cycles per unit
+    }
     const double shift = W.shift ? W.shift[pair] : 0.0; // non-zero only in the second look (asx_api.hip)
     const int M2 = P.M2, c0 = tile * T;
     const float2 *in = qi + RWS_PAIR(pair) * pair_pitch;
