@@ -556,6 +556,7 @@ __global__ __launch_bounds__(NT, 4) void k_inv_cols_r(const RArgs P, const float
     // at 300 rows (profiles/r5_experiments/02_*).
     const size_t pair = blockIdx.x;
     const int tile = rcol_tile_of_block(blockIdx.y, logT);
+    if (tile * T >= P.M2) return; // the tile count is rounded up; the tile width is this kernel's own (it reads only)
     {
         // Stagger: the blocks that share a CU run the same program -- a load phase (the tile's rows), then compute phases of about
         // the same length -- and, started together, stay in step: both wait for memory, then both compute.  The blocks of the FIRST
