@@ -664,10 +664,6 @@ __global__ __launch_bounds__(NT, 4) void k_inv_cols_r(const RArgs P, const float
         lds_last_stage_static<S1, true, true>(lds4, Lc, P.tw1, pre_last, sink);
     };
     const uint32_t uM2 = (uint32_t)M2;
-    // lag order inside a slot: re0 (i0), re1 (i0 + 1), im0 (i0 + M2), im1 (i0 + M2 + 1)
-    auto lag_of_max = [&](float4 s4, float m, uint32_t i0) {
-        return fabsf(s4.x) == m ? i0 : fabsf(s4.z) == m ? i0 + 1u : fabsf(s4.y) == m ? i0 + uM2 : i0 + uM2 + 1u;
-    };
     const bool fast = (tile != 0) && (r_out == nullptr) && shift == 0.0;
     auto examine_again = [&](float thr) __attribute__((always_inline)) {
         last_stage([&](auto RC, auto &v, int g, int pos0, int q) __attribute__((always_inline)) {
@@ -687,61 +683,59 @@ __global__ __launch_bounds__(NT, 4) void k_inv_cols_r(const RArgs P, const float
     float thr_again = 0.f;
     bool again = false;
     if (fast) {
-        float best_m = -INFINITY, second_m = -INFINITY;
-        uint32_t best_i0 = 0xFFFFFFFFu;
-        float4 gb = make_float4(0.f, 0.f, 0.f, 0.f);
+        // The scan keeps ONE number per thread: the largest |r| of its 4 R lags (NaNs drop out of fmaxf).  Which lag it was is
+        // looked up again only by a tile that can matter (below): with the tile-major launch order nearly every tile finds its
+        // maximum under the window of the running maximum it fetched at its start and is done behind one barrier -- no index,
+        // no second maximum, no atomic.  (Tracking index, slot and runner-up in the scan: 17 instead of 3 instructions per slot,
+        // k_inv_cols_r 0.353 against 0.332 ms at 600 rows, 1.15 against 1.08 ms per 1024 pairs at 400, equal at 600 x 480,
+        // 0.31 against 0.32 at 300 rows; profiles/r5_experiments/06_*.)
+        float best_m = -INFINITY;
         last_stage([&](auto RC, auto &v, int g, int pos0, int q) __attribute__((always_inline)) {
             static_for<0, decltype(RC)::value>([&](auto TT) __attribute__((always_inline)) {
                 constexpr int t = decltype(TT)::value;
-                const float4 s4 = make_float4(v[t].re.x, v[t].im.x, v[t].re.y, v[t].im.y);
-                const float m = fmaxf(fmaxf(fabsf(s4.x), fabsf(s4.y)), fmaxf(fabsf(s4.z), fabsf(s4.w))); // NaNs drop out
-                const uint32_t i0 = (uint32_t)(2 * (pos0 + t * q)) * uM2 + (uint32_t)(c0 + 2 * g);
-                if (m > best_m) { second_m = best_m; best_m = m; gb = s4; best_i0 = i0; }
-                else if (m == best_m) {
-                    // equal slot maxima (rare): the smaller lag stays; both count as near the maximum
-                    if (lag_of_max(s4, m, i0) < lag_of_max(gb, m, best_i0)) { gb = s4; best_i0 = i0; }
-                    second_m = m;
-                } else if (m > second_m) second_m = m;
+                best_m = fmaxf(fmaxf(best_m, fmaxf(fabsf(v[t].re.x), fabsf(v[t].im.x))), fmaxf(fabsf(v[t].re.y), fabsf(v[t].im.y)));
             });
         });
-        const uint32_t my_idx = lag_of_max(gb, best_m, best_i0);
         RSTAMP(2, sblock, 4);
         const float wmax = wave_max_nonneg(fmaxf(best_m, 0.f));
-        unsigned long long holders = __ballot(best_m == wmax);
-        uint32_t widx = 0xFFFFFFFFu;
-        while (holders) {
-            const int l = __ffsll((long long)holders) - 1;
-            const uint32_t li = (uint32_t)__builtin_amdgcn_readlane((int)my_idx, l);
-            widx = li < widx ? li : widx;
-            holders &= holders - 1;
-        }
-        // (Every wave publishing its own maximum and taking its own threshold -- no block-wide reduction, no barrier here --
-        //  was measured: 0.40 -> 0.95 ms, eight times the atomics on one address per pair; profiles/r4_experiments/25_*.  With the
-        //  tile-major order and a per-wave exit below run0's window it costs nothing and gains nothing: 0.366 against 0.367 ms,
-        //  profiles/r5_experiments/02_*.)
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = widx == 0xFFFFFFFFu ? 0 : peak_pack_key(wmax, widx);
+        float *redf = reinterpret_cast<float *>(red);
+        if ((threadIdx.x & 63) == 0) redf[threadIdx.x >> 6] = wmax;
         __syncthreads();
-        asx_peak_t tb = red[0];
-        for (int w = 1; w < NT / 64; w++) tb = peak_max(tb, red[w]);
-        if (threadIdx.x == 0) atomicMax(&W.pairmax[pair], tb);
-        if (W.tile_peak && best_m == wmax && my_idx == widx && tb == peak_pack_key(wmax, widx)) {
-            // the one lane that holds the tile's best lag: its SIGNED value (the key is |r|) for the spectral Pearson form
-            const float sv = fabsf(gb.x) == best_m ? gb.x : fabsf(gb.z) == best_m ? gb.z : fabsf(gb.y) == best_m ? gb.y : gb.w;
-            W.tile_peak[pair * (size_t)(P.M2 / T) + tile] = sv;
-        }
+        float bm = redf[0];
+        for (int w = 1; w < NT / 64; w++) bm = fmaxf(bm, redf[w]);
+        // the final maximum is >= run0: below run0's window nothing of this tile can be the peak or near it (run0 == 0, nothing
+        // seen yet, gives a NaN threshold: no exit)
+        if (bm < near_max_threshold(peak_key(run0), b2)) return; // block-uniform
         RSTAMP(2, sblock, 5);
-        const float thr = near_max_threshold(peak_key(peak_max(tb, run0)), b2);
-        thr_again = thr;
-        if (best_m >= thr) {
-            if (second_m >= thr) {
-                again = true;
-            } else {
-                const float val[4] = { gb.x, gb.y, gb.z, gb.w };
+        // ---- a tile that can matter (the first generation of blocks, record setters, the peak's tile): the last stage again for
+        // the threads that hold its maximum or a near-maximum -- smallest lag and signed value of the maximum, candidates.
+        // (The holders publishing for themselves, without the fold and its two barriers: the same time, and 8 bytes of scratch.)
+        const float thr = near_max_threshold(fmaxf(bm, peak_key(run0)), b2); // key(run0) is NaN when nothing was seen: fmaxf drops it
+        uint32_t my_idx = 0xFFFFFFFFu;
+        float my_val = 0.f;
+        if (best_m >= thr || best_m == bm) {
+            last_stage([&](auto RC, auto &v, int g, int pos0, int q) __attribute__((always_inline)) {
+                static_for<0, decltype(RC)::value>([&](auto TT) __attribute__((always_inline)) {
+                    constexpr int t = decltype(TT)::value;
+                    const float val[4] = { v[t].re.x, v[t].re.y, v[t].im.x, v[t].im.y }; // in lag order: i0, i0 + 1, i0 + M2, i0 + M2 + 1
+                    const uint32_t i0 = (uint32_t)(2 * (pos0 + t * q)) * uM2 + (uint32_t)(c0 + 2 * g);
 #pragma unroll
-                for (int h = 0; h < 4; h++)
-                    if (fabsf(val[h]) >= thr) cand_append(W, pair, best_i0 + (uint32_t)(h & 1) * uM2 + (uint32_t)(h >> 1), fabsf(val[h]));
-            }
+                    for (int h = 0; h < 4; h++) {
+                        const uint32_t idx = i0 + (uint32_t)(h >> 1) * uM2 + (uint32_t)(h & 1);
+                        const float a = fabsf(val[h]);
+                        if (a == bm && idx < my_idx) { my_idx = idx; my_val = val[h]; }
+                        if (a >= thr) cand_append(W, pair, idx, a);
+                    }
+                });
+            });
         }
+        __syncthreads(); // redf is read by every thread above
+        const asx_peak_t mine = my_idx == 0xFFFFFFFFu ? 0 : peak_pack_key(bm, my_idx);
+        const asx_peak_t tb = block_peak_max(mine, red);
+        if (threadIdx.x == 0) { atomicMax(&W.pairmax[pair], tb); red[0] = tb; }
+        __syncthreads();
+        // the one thread that holds the tile's best lag: its SIGNED value (the key is |r|) for the spectral Pearson form
+        if (W.tile_peak && mine != 0 && mine == red[0]) W.tile_peak[pair * (size_t)(P.M2 / T) + tile] = my_val;
     } else {
         // general form: first tile (lag 0 competes signed), r dumped for tests, shifted keys of the second look
         float best_key = -INFINITY, best_val = 0.f;
