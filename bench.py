@@ -87,7 +87,12 @@ def cpu_quota():
     return n
 
 
-def _baseline_worker(n, pairs, rounds, first, ready, go, out):
+def _baseline_worker(n, pairs, rounds, first, cpu, ready, go, out):
+    if cpu is not None:
+        try:
+            os.sched_setaffinity(0, {cpu})     # one worker per CPU, evenly spread over the usable set: no migration, no sharing
+        except (AttributeError, OSError):
+            pass
     import oracle
     w = oracle.Worker(n)
     w.run(*pairs[first % len(pairs)])          # touch every buffer once: page faults stay out of the timed region
@@ -100,12 +105,24 @@ def _baseline_worker(n, pairs, rounds, first, ready, go, out):
     out.put(done)
 
 
+def _spread_cpus(workers):
+    """`workers` CPUs of this process's affinity set, evenly spaced (SMT siblings and neighbours last)"""
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        return [None] * workers
+    if workers > len(cpus):
+        return [cpus[i % len(cpus)] for i in range(workers)]
+    return [cpus[(i * len(cpus)) // workers] for i in range(workers)]
+
+
 def _throughput(n, pairs, workers, rounds):
-    """`workers` independent single-threaded PROCESSES (one per core), each making `rounds` calls on its own buffers"""
+    """`workers` independent single-threaded PROCESSES, each pinned to its own CPU, each making `rounds` calls on its own buffers"""
     import multiprocessing as mp
     ctx = mp.get_context("fork")               # no GPU context exists in this process yet (see main())
     ready, go, out = ctx.Barrier(workers + 1), ctx.Event(), ctx.Queue()
-    procs = [ctx.Process(target=_baseline_worker, args=(n, pairs, rounds, i, ready, go, out)) for i in range(workers)]
+    cpus = _spread_cpus(workers)
+    procs = [ctx.Process(target=_baseline_worker, args=(n, pairs, rounds, i, cpus[i], ready, go, out)) for i in range(workers)]
     for p in procs:
         p.start()
     ready.wait()
@@ -118,15 +135,17 @@ def _throughput(n, pairs, workers, rounds):
     return done / dt, dt, done
 
 
-def cpu_baseline(sample_len, seconds_budget=28.0):
+def cpu_baseline(sample_len, point_seconds=3.0, sweeps=3):
     """The reference's CPU path on this node's host cores (oracle/cpu_baseline.c), run BEFORE this process touches the
     GPU.  (i) faithful single-call latency -- two threads for the forward transforms, plans and allocations per call, the
     cost model of src/cross_correlation.c:33-36,159-239 -- at N and at BASELINE configs[0]'s N = 144 000; (ii) node
-    throughput -- independent single-threaded worker processes, one per core, plans and buffers kept between calls
-    (BASELINE.md section 4), swept over the worker count; `value` is the best point.  Backend: FFTW3 if libfftw3.so.3 can
-    be dlopen()ed here, else the oracle's own DFT (labelled)."""
+    throughput -- independent single-threaded worker processes, one per CPU and pinned to it, plans and buffers kept
+    between calls.  Three worker counts (half of, all of, twice the usable CPUs), each measured for
+    >= `point_seconds` of wall time per sweep, `sweeps` sweeps; a point's rate is the MEDIAN of its sweeps, `value` the
+    best point, `spread` (max - min) / median of that point over the sweeps (round 4's points ran 0.4-1.8 s
+    once, and moved 1.6x between rounds).  Backend: FFTW3 if libfftw3.so.3 can be dlopen()ed here, else the oracle's own
+    DFT (labelled).  About 30-40 s in all."""
     import oracle
-    t_start = time.perf_counter()
     cores, usable = os.cpu_count() or 1, cpu_quota()
     backend = oracle.baseline_backend()
     distinct = 8
@@ -153,32 +172,31 @@ def cpu_baseline(sample_len, seconds_budget=28.0):
     t_worker = time.perf_counter() - t0
     w1.close()
     del w1
-    # sweep: powers of two up to the usable CPUs (and one step beyond: SMT siblings), best point wins
-    cands = sorted({c for c in (1, 2, 4, 8, 16, 32, 64, 128, 256, usable, min(2 * usable, cores)) if 1 <= c <= max(usable, min(2 * usable, cores))})
-    if len(cands) > 6:
-        cands = cands[-6:]
-    sweep, best = [], None
+    cands = sorted({c for c in (max(1, usable // 2), usable, min(2 * usable, cores)) if c >= 1})
+    rounds = max(2, int(point_seconds / max(t_worker, 1e-3) + 0.999))   # calls per worker and point: >= point_seconds of wall time
+    runs = {wk: [] for wk in cands}
+    for _ in range(sweeps):
+        for wk in cands:
+            rate, dt, done = _throughput(sample_len, pairs, wk, rounds)
+            runs[wk].append({"calls": done, "seconds": round(dt, 3), "per_s": round(rate, 2)})
+    points = []
     for wk in cands:
-        left = seconds_budget - (time.perf_counter() - t_start)
-        if left < 3.0 * t_worker + 1.0:
-            break
-        rounds = max(1, min(4, int(left / max(1, len(cands) - len(sweep)) / (2.0 * t_worker))))
-        rate, dt, done = _throughput(sample_len, pairs, wk, rounds)
-        sweep.append({"workers": wk, "calls": done, "seconds": round(dt, 3), "per_s": round(rate, 2)})
-        if best is None or rate > best[0]:
-            best = (rate, wk, done, dt)
-    rate, wk, done, dt = best
-    return {"value": rate, "unit": "cross-correlations/s", "cores": wk,
+        rates = sorted(r["per_s"] for r in runs[wk])
+        med = statistics.median(rates)
+        points.append({"workers": wk, "per_s": med, "spread": round((rates[-1] - rates[0]) / med, 4) if med else None,
+                       "sweeps": runs[wk]})
+    best = max(points, key=lambda p: p["per_s"])
+    return {"value": best["per_s"], "unit": "cross-correlations/s", "cores": best["workers"], "spread": best["spread"],
             "kind": "reference" if backend == "fftw3" else "port", "backend": backend,
-            "nproc": cores, "usable_cpus": usable, "cpu_model": cpu_model(), "sweep": sweep,
+            "nproc": cores, "usable_cpus": usable, "cpu_model": cpu_model(), "sweep": points,
             "single_call_latency_s": one, "single_call_latency_s_N144000": one_small,
             "worker_call_s": t_worker,
             "single_call_model": "2 threads for the forward transforms, plan + 4 allocations per call "
                                  "(src/cross_correlation.c:33-36,159-239)",
-            "sample": "%d calls of N=%d (float32 values widened to float64) by %d single-threaded worker processes "
-                      "(plans and buffers kept per worker), %d distinct pairs, %.1f s, best of a sweep over the worker count; "
-                      "taken before the first GPU call; backend %s" %
-                      (done, sample_len, wk, distinct, dt,
+            "sample": "%d calls of N=%d (float32 values widened to float64) per sweep by %d single-threaded worker processes, each "
+                      "pinned to its own CPU (plans and buffers kept per worker), %d distinct pairs, >= %.0f s per point, median of %d "
+                      "sweeps over three worker counts, best point; taken before the first GPU call; backend %s" %
+                      (best["sweeps"][0]["calls"], sample_len, best["workers"], distinct, point_seconds, sweeps,
                        "FFTW3 (dlopen libfftw3.so.3)" if backend == "fftw3" else "oracle/fft64.c (no libfftw3 on this node)")}
 
 
@@ -585,6 +603,9 @@ def run_rank(args, cpu=None):
                 "metric": "cross-correlations/sec (N=%d float32 pairs)" % n,
                 "value": value, "unit": "cross-correlations/s", "n_gpus": world, "steps": args.steps,
                 "warmup": args.warmup, "preconditioning_steps": pre,
+                # every untimed step that ran in front of the region `value` times: the W + K steps of the un-preconditioned leg
+                # (`value_no_precondition`, taken first), then `pre` + W more
+                "untimed_steps_before_value": (args.warmup + args.steps) + pre + args.warmup,
                 "ms_per_step": dt / args.steps * 1e3,
                 "value_no_precondition": batch * world * args.steps / dt_cold,
                 "ms_per_step_no_precondition": dt_cold / args.steps * 1e3,
