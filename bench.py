@@ -15,6 +15,8 @@ Workloads
   config4   (the JSON line's `config4` object)  BASELINE.json configs[3] as written: a FIXED batch of
             8192 pairs, N = 480 000, block-partitioned over the ranks (strong scaling), inputs
             generated on the device per shard, the same gather.
+  config4_capi  the same batch through the C-ABI's own multi-device form (ONE process, asx_comm_create over
+            one plan per GPU, asx_xcorr_batch_multi_dev): rank 0 runs it behind the distributed legs.
 
 Ranks: `--gpus N` with N > 1 and no WORLD_SIZE in the environment starts N ranks itself
 (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`, one process per GPU)
@@ -288,6 +290,75 @@ def single_pair_latency(asx, torch, src32, smp32, n, reps, split=None):
 
 
 # --------------------------------------------------------------------------------------------------
+# BASELINE configs[3] through the C-ABI's own multi-device form: ONE process, one plan per GPU, asx_comm_create +
+# asx_xcorr_batch_multi_dev (csrc/asx_api.hip: a host thread and a stream per device, one ncclAllGather of the result records
+# inside the library).  The torch.distributed form above it is the headline's; this leg exists so that a multi-GPU run measures
+# BOTH forms without a code change.  With one GPU the communicator has one rank.
+# --------------------------------------------------------------------------------------------------
+def capi_leg(ngpus, steps):
+    import numpy as np
+    import torch
+    import __graft_entry__ as graft
+    asx = graft.load()
+    n, total = CONFIG4_N, CONFIG4_BATCH
+    width = (total + ngpus - 1) // ngpus
+    rec = asx.result_bytes(width)
+    plans, srcs, smps, trues, gathered, counts = [], [], [], [], [], []
+    for g in range(ngpus):
+        start, count = asx.shard_range(total, ngpus, g)
+        with torch.cuda.device(g):
+            c = max(count, 1)
+            d_src = torch.empty(c * 2 * n, dtype=torch.float32, device="cuda")
+            d_smp = torch.empty(c * n, dtype=torch.float32, device="cuda")
+            d_true = torch.full((width,), 0, dtype=torch.int64, device="cuda")
+            if count:
+                asx.synth_pairs_dev(SEED, start, count, n, 0, d_src.data_ptr(), d_smp.data_ptr(), d_true.data_ptr(), 0)
+            torch.cuda.synchronize()
+            plans.append(asx.Plan(n, c, g))
+            gathered.append(torch.zeros(ngpus * rec, dtype=torch.uint8, device="cuda"))
+        srcs.append(d_src); smps.append(d_smp); trues.append(d_true); counts.append(count)
+    comm = asx.Comm(plans)
+    args = ([t.data_ptr() for t in srcs], [t.data_ptr() for t in smps], counts, width, [t.data_ptr() for t in gathered])
+    comm.run(*args)                                   # warm-up (communicator, clocks)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        comm.run(*args)                               # returns after every device's stream has been synchronised
+    dt = time.perf_counter() - t0
+    ok = True
+    for dev in range(ngpus):                          # every device holds the record of every shard
+        g_all = gathered[dev].cpu().numpy()
+        for sh in range(ngpus):
+            r = g_all[sh * rec: (sh + 1) * rec]
+            lag = r[: 8 * width].view(np.int64); ret = r[16 * width: 20 * width].view(np.int32)
+            ok = ok and bool(np.array_equal(lag[: counts[sh]], trues[sh].cpu().numpy()[: counts[sh]])) and not ret[: counts[sh]].any()
+    comm.close()
+    for p_ in plans:
+        p_.close()
+    return {"metric": "cross-correlations/sec (fixed batch %d x N=%d, C-ABI multi-device form)" % (total, n),
+            "value": total * steps / dt, "unit": "cross-correlations/s", "scaling": "strong", "n_gpus": ngpus, "steps": steps,
+            "ms_per_step": dt / steps * 1e3, "pairs_total": total, "results_ok": ok,
+            "path_frac_of_hbm_roofline": BYTES_PER_FRAME * n * total * steps / dt / ngpus / 1e9 / HBM_PEAK_GBS,
+            "workload": "BASELINE configs[3] in ONE process: asx_comm_create over %d plan(s), asx_xcorr_batch_multi_dev "
+                        "(one host thread + stream per device, ncclAllGather of the result records inside the library)" % ngpus}
+
+
+def capi_leg_guarded(ngpus, steps, in_process):
+    """in-process with one GPU; as a child process with a time limit otherwise: the N > 1 form of this leg has never met a second
+    GPU (no multi-GPU node was available to any round), and a fault in it must not take the headline line down with it"""
+    try:
+        if in_process:
+            return capi_leg(ngpus, steps)
+        cmd = [sys.executable, os.path.abspath(__file__), "--mode", "capi", "--gpus", str(ngpus), "--steps4", str(steps)]
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+        lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+        if p.returncode != 0 or not lines:
+            return {"error": "child exited with %d: %s" % (p.returncode, p.stderr[-500:])}
+        return json.loads(lines[-1])
+    except Exception as e:      # noqa: BLE001 -- reported in the line, never fatal
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+
+
+# --------------------------------------------------------------------------------------------------
 # ranks
 # --------------------------------------------------------------------------------------------------
 def free_port():
@@ -547,6 +618,13 @@ def run_rank(args, cpu=None):
             w4.close()
             torch.cuda.empty_cache()
 
+        cfg4c = None
+        if not args.no_config4 and not args.no_capi:
+            if multi:
+                dist.barrier()        # every rank has released its config4 buffers
+            if rank == 0:
+                cfg4c = capi_leg_guarded(world, args.steps4, in_process=(world == 1))
+
         single = None
         if world == 1 and not args.no_single:
             import numpy as np
@@ -625,6 +703,8 @@ def run_rank(args, cpu=None):
             }
             if cfg4 is not None:
                 line["config4"] = cfg4
+            if cfg4c is not None:
+                line["config4_capi"] = cfg4c
             if single is not None:
                 line["single_pair"] = single
     if rank == 0:
@@ -650,16 +730,20 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-config4", action="store_true", help="skip the fixed-batch 8192 x 480000 leg")
     ap.add_argument("--no-single", action="store_true", help="skip the single-pair latency leg")
+    ap.add_argument("--no-capi", action="store_true", help="skip the C-ABI multi-device form of the config4 leg")
     ap.add_argument("--steps4", type=int, default=3, help="timed steps of the config4 leg")
     ap.add_argument("--profile-steps", type=int, default=0,
                     help="steps of the per-kernel HIP-event window (0 = max(20, steps) behind 10 lead steps); counter-collection "
                          "runs (tools/traffic.sh, tools/pmc.sh), where every launch is serialised, pass a small number")
     ap.add_argument("--split", default=None)
     ap.add_argument("--dry-run", action="store_true", help="rank/shard/gather path on CPU with gloo, no GPU")
-    ap.add_argument("--mode", default="batched", choices=["batched", "streaming", "single"],
+    ap.add_argument("--mode", default="batched", choices=["batched", "streaming", "single", "capi"],
                     help="batched = the headline workload (default); streaming = BASELINE config 5 "
                          "(growing window 3..30 s, plan reuse); single = config 2 (one pair, latency)")
     args = ap.parse_args()
+    if args.mode == "capi":      # child of rank 0 (capi_leg_guarded): config4 through asx_comm_create / asx_xcorr_batch_multi_dev
+        print(json.dumps(capi_leg(args.gpus, args.steps4)), flush=True)
+        return 0
     if args.mode != "batched":
         return side_mode(args)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:

@@ -69,6 +69,12 @@ asx_plan *asx_plan_create(size_t sample_len, size_t max_batch, int device);
  * "auto" = the planner's cost model (tuned table for the reference's six lengths).
  * $ASX_SPLIT supplies the value when the argument is NULL or "". */
 asx_plan *asx_plan_create_ex(size_t sample_len, size_t max_batch, int device, const char *split);
+/* "measure" plans only, once, at their first asx_xcorr_batch_f32_dev call: the forward column kernel is timed against the
+ * caller's buffers on two allocations of its output workspaces and the faster set is kept (the kernel runs 2-5 % apart with
+ * the physical placement of the buffers it streams together; offsets inside an allocation change nothing).  A few
+ * milliseconds and, transiently, a second set of workspaces.  asx_plan_placement: the two times in ms (0 = not measured)
+ * and which set was kept (0 = the first, 1 = the second, -1 = not measured).  Plans of every other mode never do this. */
+int asx_plan_placement(asx_plan *plan, double ms[2], int *kept);
 void asx_plan_destroy(asx_plan *plan);
 
 /* Peak search exactness (replaces max_abs_index(), src/cross_correlation.c:52-67, a float64 scan).

@@ -131,6 +131,11 @@ struct asx_plan {
     bool spectral = false;             // float32 groups take the spectral Pearson form (asx_plan_set_pearson; real-column plans)
     unsigned long long *mode_count = nullptr; // [ASX_PM_NMODES], cumulative over the plan's life
     bool q_inplace = false;            // k_rows_r writes Q over the rows of C_x it has just read (rlayout only)
+    // "measure" plans only: at the first device-resident batch the forward column kernel is timed against the caller's buffers
+    // on TWO allocations of its output workspaces and the faster set is kept (tune_placement)
+    bool tune_placement = false, placement_done = false;
+    double placement_ms[2] = { 0.0, 0.0 };
+    int placement_kept = -1;
     // staging for the host-pointer entry points (lazy)
     float *st_src = nullptr, *st_smp = nullptr;
     int64_t *st_lag = nullptr;
@@ -377,7 +382,9 @@ extern "C" asx_plan *asx_plan_create_ex(size_t sample_len, size_t max_batch, int
         const std::string best = measure_best_split(sample_len, max_batch ? max_batch : 1, dev);
         (void)hipSetDevice(prev);
         // an empty result (nothing could be timed) falls back to the planner's own choice
-        return asx_plan_create_ex(sample_len, max_batch, device, best.empty() ? "auto" : best.c_str());
+        asx_plan *mp = asx_plan_create_ex(sample_len, max_batch, device, best.empty() ? "auto" : best.c_str());
+        if (mp) mp->tune_placement = true;
+        return mp;
     }
     if (split && !strcmp(split, "auto")) split = "";
     int ndev = 0;
@@ -741,6 +748,68 @@ static int resolve_overflows(asx_plan *p, const float *f_smp, const TIn *p_src, 
     return (int)n;
 }
 
+// The forward column kernel runs 2-5 % faster or slower with the PHYSICAL placement of the buffers it streams together (the
+// caller's inputs read, C_x / C_y written): strictly alternating with every re-allocation of either side, whatever the
+// allocator, and untouched by offsets inside an allocation (EXPERIMENTS.md, round 4 items 27-28).  Nothing the library lays
+// out can steer that -- but a plan made with split = "measure" (FFTW_MEASURE's role) may spend a few milliseconds once: at its
+// first device-resident batch it allocates C_x / C_y a second time, times k_fwd_cols against the caller's buffers on both sets
+// and keeps the faster.  The default planning mode never does this.
+static int tune_placement(asx_plan *p, const float *d_src, const float *d_smp, size_t g, hipStream_t s)
+{
+    p->placement_done = true;
+    const AsxDev &P = p->dev;
+    asx_plan::Lane &W = p->lanes[0];
+    const size_t mz = ((size_t)p->host.M1 + 1) * (size_t)p->host.M2 * p->group;
+    float2 *alt[2] = { nullptr, nullptr };
+    if (hipMalloc((void **)&alt[0], mz * sizeof(float2)) != hipSuccess || hipMalloc((void **)&alt[1], mz * sizeof(float2)) != hipSuccess) {
+        (void)hipGetLastError();
+        if (alt[0]) (void)hipFree(alt[0]);
+        return 0; // no room for a second set: keep what there is
+    }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    AsxPeakWs tk = W.pk;
+    tk.band = nullptr; tk.tile_peak = nullptr;
+    float2 *set[2][2] = { { W.zxa, W.zya }, { alt[0], alt[1] } };
+    for (int k = 0; k < 2; k++) {
+        float best = 0.f;
+        for (int r = 0; r < 4; r++) { // the first launch warms the set up; the fastest of the other three counts
+            HIP_TRY(hipEventRecord(e0, s));
+            asx_launch_fwd_cols(P, d_src, d_smp, set[k][0], set[k][1], tk, (int)g, s);
+            HIP_TRY(hipEventRecord(e1, s));
+            HIP_TRY(hipEventSynchronize(e1));
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+            if (r >= 1 && (best == 0.f || ms < best)) best = ms;
+        }
+        p->placement_ms[k] = best;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    const int keep = p->placement_ms[1] < 0.995 * p->placement_ms[0] ? 1 : 0;
+    p->placement_kept = keep;
+    for (int i = 0; i < 2; i++) {
+        float2 *drop = set[1 - keep][i];
+        auto it = std::find(p->allocs.begin(), p->allocs.end(), (void *)drop);
+        if (it != p->allocs.end()) p->allocs.erase(it);
+        (void)hipFree(drop);
+        if (keep == 1) p->allocs.push_back(set[1][i]);
+    }
+    W.zxa = set[keep][0];
+    W.zya = set[keep][1];
+    return 0;
+}
+
+extern "C" int asx_plan_placement(asx_plan *p, double ms[2], int *kept)
+{
+    if (!p || !ms || !kept) return fail("asx_plan_placement: null argument");
+    std::lock_guard<std::mutex> guard(p->lock);
+    ms[0] = p->placement_ms[0]; ms[1] = p->placement_ms[1];
+    *kept = p->placement_kept;
+    return 0;
+}
+
 extern "C" int asx_xcorr_batch_f32_dev(asx_plan *p, const float *d_source, const float *d_sample,
                                        size_t batch, int64_t *d_lag, double *d_coef, int32_t *d_ret,
                                        void *stream)
@@ -751,6 +820,9 @@ extern "C" int asx_xcorr_batch_f32_dev(asx_plan *p, const float *d_source, const
     if (!dg.ok) return fail("cannot select device %d", p->device);
     hipStream_t s = stream ? (hipStream_t)stream : p->stream;
     const size_t N = p->host.N;
+    if (p->tune_placement && !p->placement_done && p->nlanes == 1 && batch >= std::min<size_t>(p->group, 8) &&
+        tune_placement(p, d_source, d_sample, std::min(batch, p->group), s))
+        return -1;
     prof_begin_call(p);
     // chunking: groups of at most `group` pairs; with two lanes a batch is cut into at least two
     // chunks (when it is big enough to fill the chip twice) that alternate between the lanes

@@ -1,6 +1,8 @@
 // csrc/host_narrow.cpp -- see host_narrow.h.  Plain C++ threads; no HIP.
 #include "host_narrow.h"
 
+#include <unistd.h>
+
 #include <atomic>
 #include <stdint.h>
 #if defined(__x86_64__)
@@ -100,27 +102,37 @@ struct Pool {
         }
         if (const char *e = getenv("ASX_HOST_THREADS")) nt = atoi(e);
         if (nt < 1) nt = 1;
+        if (nt > 64) nt = 64; // whatever the environment says
+        owner = getpid();
         for (int i = 0; i < nt; i++) workers.emplace_back([this] { run(); });
     }
+    // Threads do not survive fork(): in a child of the process that built the pool (Python multiprocessing with the fork start
+    // method, for one) nobody would ever take a posted job.  There the caller converts every chunk itself (work_one below).
+    pid_t owner = 0;
+    bool alive() const { return getpid() == owner; }
     ~Pool()
     {
         { std::lock_guard<std::mutex> g(m); stop = true; }
         cv.notify_all();
         for (std::thread &t : workers) t.join();
     }
+    // takes the next unclaimed chunk of the current job, if there is one
+    bool work_one()
+    {
+        const size_t c = next.fetch_add(1);
+        if (c >= nchunks) return false;
+        int state = 2;
+        if (!bad.load(std::memory_order_relaxed)) {
+            const size_t off = c * CHUNK, len = off + CHUNK <= n ? CHUNK : n - off;
+            if (narrow_chunk(src + off, dst + off, len)) state = 1;
+            else bad.store(true);
+        }
+        done[c].store(state, std::memory_order_release);
+        return true;
+    }
     void work()
     {
-        for (;;) {
-            const size_t c = next.fetch_add(1);
-            if (c >= nchunks) return;
-            int state = 2;
-            if (!bad.load(std::memory_order_relaxed)) {
-                const size_t off = c * CHUNK, len = off + CHUNK <= n ? CHUNK : n - off;
-                if (narrow_chunk(src + off, dst + off, len)) state = 1;
-                else bad.store(true);
-            }
-            done[c].store(state, std::memory_order_release);
-        }
+        while (work_one()) {}
     }
     void run()
     {
@@ -158,24 +170,36 @@ int asx_narrow_exact(const double *src, float *dst, size_t n, asx_narrow_ready_f
     for (size_t c = 0; c < nchunks; c++) P.done[c].store(0, std::memory_order_relaxed);
     P.src = src; P.dst = dst; P.n = n; P.nchunks = nchunks;
     P.next.store(0); P.bad.store(false);
-    {
-        std::lock_guard<std::mutex> g(P.m);
-        P.active = (int)P.workers.size();
-        P.gen++;
+    const bool alive = P.alive();
+    if (alive) {
+        {
+            std::lock_guard<std::mutex> g(P.m);
+            P.active = (int)P.workers.size();
+            P.gen++;
+        }
+        P.cv.notify_all();
+    } else {
+        P.active = 0; // a forked child: no worker threads here
     }
-    P.cv.notify_all();
-    // the caller hands finished chunks on, in order, while the workers convert the later ones
+    // The caller hands finished chunks on, in order, while the workers convert the later ones.  While the chunk it needs is
+    // still pending it converts chunks itself instead of spinning: under a one-CPU quota a spinning caller competes with the
+    // very workers it waits for, and in a forked child it is the only thread there is.
+    auto wait_chunk = [&](size_t i) {
+        int st;
+        while ((st = P.done[i].load(std::memory_order_acquire)) == 0)
+            if (!P.work_one()) std::this_thread::yield();
+        return st;
+    };
     bool ok = true;
     size_t c = 0;
     while (c < nchunks && ok) {
-        int st;
-        while ((st = P.done[c].load(std::memory_order_acquire)) == 0) std::this_thread::yield();
+        int st = wait_chunk(c);
         if (st != 1) { ok = false; break; }
         // at least MIN_RUN chunks per hand-over (every hipMemcpyAsync costs the caller microseconds), plus whatever else
         // is finished already
         size_t e = c + 1;
         while (e < nchunks && e - c < MIN_RUN) {
-            while ((st = P.done[e].load(std::memory_order_acquire)) == 0) std::this_thread::yield();
+            st = wait_chunk(e);
             if (st != 1) break;
             e++;
         }
@@ -187,7 +211,7 @@ int asx_narrow_exact(const double *src, float *dst, size_t n, asx_narrow_ready_f
         c = e;
     }
     // every worker has left the job before the next one may be posted (and before src / dst may go away)
-    {
+    if (alive) {
         std::unique_lock<std::mutex> g(P.m);
         P.cv_done.wait(g, [&] { return P.active == 0; });
     }

@@ -25,7 +25,7 @@ ABI_SYMBOLS = [
     "asx_plan_last_timings_ms", "asx_device_malloc", "asx_device_free", "asx_memcpy_h2d",
     "asx_memcpy_d2h", "asx_stream_sync", "asx_plan_peak_overflows", "asx_plan_peak_repairs", "asx_plan_set_exact", "asx_plan_peak_capacity",
     "asx_current_device", "asx_plan_timings_ms", "asx_xcorr_batch_multi", "asx_plan_layout", "asx_plan_narrowed_calls",
-    "asx_plan_set_pearson", "asx_plan_pearson_modes", "asx_host_malloc", "asx_host_free", "asx_shard_range", "asx_result_bytes", "asx_comm_create", "asx_comm_destroy", "asx_xcorr_batch_multi_dev",
+    "asx_plan_set_pearson", "asx_plan_pearson_modes", "asx_plan_placement", "asx_host_malloc", "asx_host_free", "asx_shard_range", "asx_result_bytes", "asx_comm_create", "asx_comm_destroy", "asx_xcorr_batch_multi_dev",
 ]
 
 
@@ -71,6 +71,8 @@ def lib():
     L.asx_plan_peak_overflows.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
     L.asx_plan_set_exact.restype = ctypes.c_int
     L.asx_plan_set_exact.argtypes = [vp, ctypes.c_int]
+    L.asx_plan_placement.restype = ctypes.c_int
+    L.asx_plan_placement.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]
     L.asx_plan_set_pearson.restype = ctypes.c_int
     L.asx_plan_set_pearson.argtypes = [vp, ctypes.c_int]
     L.asx_plan_pearson_modes.restype = ctypes.c_int
@@ -418,6 +420,14 @@ class Plan:
         once per call for its kernels); off: that entry point stays asynchronous and marks such pairs with ret = 1"""
         if lib().asx_plan_set_exact(self._h, 1 if on else 0) != 0:
             raise AsxError(_err())
+
+    def placement(self):
+        """("measure" plans) -> ((ms of the forward column kernel on the first / second allocation of its workspaces), kept)"""
+        ms = (ctypes.c_double * 2)()
+        kept = ctypes.c_int(-1)
+        if lib().asx_plan_placement(self._h, ms, ctypes.byref(kept)) != 0:
+            raise AsxError(_err())
+        return (float(ms[0]), float(ms[1])), int(kept.value)
 
     def set_pearson(self, spectral=True):
         """spectral (the default on real-column plans): the coefficient from r[peak] and the forward pass's band sums, no second

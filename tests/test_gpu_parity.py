@@ -756,3 +756,38 @@ def test_measured_mode_plan_matches_oracle(mod):
         o_ret, o_lag, o_coef = oracle.cross_correlation(s, t)
         assert int(ret[i]) == o_ret and int(lag[i]) == o_lag
         assert abs(float(coef[i]) - o_coef) < COEF_TOL
+
+
+def test_measure_plans_pick_the_faster_placement_of_their_workspaces(mod, torch):
+    """split = "measure" (FFTW_MEASURE's role; default plans never do this): at the first device-resident batch the forward
+    column kernel is timed against the caller's buffers on two allocations of its output workspaces, the faster set stays
+    (VERDICT r4 #8; EXPERIMENTS.md round 4, items 27-28); results are what they were"""
+    n, batch = 144000, 64
+    d_src = torch.empty(batch * 2 * n, dtype=torch.float32, device="cuda")
+    d_smp = torch.empty(batch * n, dtype=torch.float32, device="cuda")
+    d_true = torch.empty(batch, dtype=torch.int64, device="cuda")
+    mod.synth_pairs_dev(77, 0, batch, n, 1, d_src.data_ptr(), d_smp.data_ptr(), d_true.data_ptr(), 0)
+    d_lag = torch.zeros(batch, dtype=torch.int64, device="cuda"); d_coef = torch.zeros(batch, dtype=torch.float64, device="cuda")
+    d_ret = torch.ones(batch, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    with mod.Plan(n, batch, 0) as plain:
+        plain.xcorr_batch_dev(d_src.data_ptr(), d_smp.data_ptr(), batch, d_lag.data_ptr(), d_coef.data_ptr(), d_ret.data_ptr())
+        plain.sync()
+        assert plain.placement() == ((0.0, 0.0), -1)
+        want = d_coef.clone()
+    with mod.Plan(n, batch, 0, split="measure") as plan:
+        assert plan.placement() == ((0.0, 0.0), -1)
+        for _ in range(2):
+            d_lag.zero_(); d_coef.zero_(); d_ret.fill_(1)
+            plan.xcorr_batch_dev(d_src.data_ptr(), d_smp.data_ptr(), batch, d_lag.data_ptr(), d_coef.data_ptr(), d_ret.data_ptr())
+            plan.sync()
+            (ms0, ms1), kept = plan.placement()
+            assert ms0 > 0 and ms1 > 0 and kept == (1 if ms1 < 0.995 * ms0 else 0)
+            assert torch.equal(d_lag, d_true) and int(d_ret.abs().sum()) == 0
+            if plan.split == plain_split(mod, n):
+                assert torch.equal(d_coef, want)          # same split, same kernels: same bits wherever the workspaces lie
+
+
+def plain_split(mod, n):
+    with mod.Plan(n, 1, 0) as p:
+        return p.split
