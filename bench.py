@@ -176,7 +176,8 @@ def cpu_baseline(sample_len, point_seconds=3.0, sweeps=3):
     del w1
     cands = sorted({c for c in (max(1, usable // 2), usable, min(2 * usable, cores)) if c >= 1})
     rounds = max(2, int(point_seconds / max(t_worker, 1e-3) + 0.999))   # calls per worker and point: >= point_seconds of wall time
-    runs = {wk: [] for wk in cands}
+    _throughput(sample_len, pairs, usable, max(2, rounds // 3))         # one untimed point: page cache, clocks (the first sweep of
+    runs = {wk: [] for wk in cands}                                     # every point ran 10-30 % low without it)
     for _ in range(sweeps):
         for wk in cands:
             rate, dt, done = _throughput(sample_len, pairs, wk, rounds)
@@ -598,6 +599,7 @@ def run_rank(args, cpu=None):
         ok = w.verify()
         plan_group, plan_split, plan_threads, plan_layout = w.plan.group, w.plan.split, w.plan.threads, w.plan.layout
         overflows = w.plan.peak_overflows()
+        spectral_modes = list(w.plan.pearson_modes()) if plan_layout == "real-column" and os.environ.get("ASX_PEARSON") != "direct" else None
         w.close()
         torch.cuda.empty_cache()
 
@@ -658,8 +660,14 @@ def run_rank(args, cpu=None):
             for k in ("fwd_cols", "rows", "inv_cols", "pearson"):
                 kb = ALGO_SHARE[k] * n * per_launch_pairs
                 ka = kb / (med[k] / groups * 1e-3) / 1e9
-                per_kernel["k_" + k + (suffix if k != "pearson" else "_partial")] = {
-                    "algorithmic_bytes_per_launch": kb, "avg_launch_ms": med[k] / groups, "achieved": ka, "frac": ka / HBM_PEAK_GBS}
+                e = {"algorithmic_bytes_per_launch": kb, "avg_launch_ms": med[k] / groups, "achieved": ka, "frac": ka / HBM_PEAK_GBS}
+                if k == "pearson" and spectral_modes is not None:
+                    # the spectral form does not MOVE the 8 N bytes of the reference's reduction (it takes r[peak] and band sums the
+                    # forward pass kept): their quotient by the family's time is work per second, not a bandwidth
+                    e["frac"] = None
+                    e["note"] = ("spectral Pearson form: pairs by form (spectral, + wrap-around correction, direct) = %s; "
+                                 "`achieved` is algorithmic bytes per second, not bytes moved" % (spectral_modes,))
+                per_kernel["k_" + k + (suffix if k != "pearson" else "_partial")] = e
             roofline = {
                 "bound": "hbm", "kernel": "k_" + dom + (suffix if dom != "pearson" else "_partial"), "achieved": achieved,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -693,6 +701,9 @@ def run_rank(args, cpu=None):
                                        "48 kHz mono float32, planted delays, SNR 0 dB" % (n, batch),
                            "sample_len": n, "pairs_per_gpu": batch, "group": plan_group,
                            "split": split, "threads_cols_rows": list(plan_threads), "layout": plan_layout,
+                           "pearson": ("spectral form with a per-pair error bound <= 1e-5, direct reduction otherwise "
+                                       "(include/audiosync/xcorr_hip.h: asx_plan_set_pearson)" if spectral_modes is not None
+                                       else "direct reduction over the segments"),
                            "exact": "every pair's lag is the float64 argmax by construction: overflowed near-tie lists are "
                                     "looked at again behind the last launch group (one host synchronisation per step, inside "
                                     "the timed region)",

@@ -35,32 +35,17 @@ struct Acc2 {
     double s1, s2;
 };
 
-// block-wide sum of (s1, s2), fixed order (lane tree, then waves in order); valid in every thread
-__device__ __forceinline__ Acc2 block_sum2(Acc2 v, double (*red)[ASX_PREP_THREADS / 64])
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        v.s1 += __shfl_xor(v.s1, off, 64);
-        v.s2 += __shfl_xor(v.s2, off, 64);
-    }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    __syncthreads(); // the previous use of `red`
-    if (lane == 0) { red[0][wave] = v.s1; red[1][wave] = v.s2; }
-    __syncthreads();
-    Acc2 t{ red[0][0], red[1][0] };
-    for (int w = 1; w < ASX_PREP_THREADS / 64; w++) { t.s1 += red[0][w]; t.s2 += red[1][w]; }
-    return t;
-}
-
 __device__ __forceinline__ void acc1(Acc2 &a, float f)
 {
     const double v = (double)f;
     a.s1 += v;
     a.s2 = fma(v, v, a.s2);
 }
+__device__ __forceinline__ void acc4(Acc2 &a, float4 v) { acc1(a, v.x); acc1(a, v.y); acc1(a, v.z); acc1(a, v.w); }
 
 // sum and sum of squares of track[lo .. hi) (float64 from the float32 samples), this thread's share: 16-byte loads over the
-// aligned middle (the track starts on a 16-byte boundary: 2N and N are multiples of four), the ragged ends by single lanes
+// aligned middle (the track starts on a 16-byte boundary: 2N and N are multiples of four), the ragged ends by single lanes.
+// Four loads in flight per thread, each into its own accumulator (a fixed order all the same: the four are added at the end).
 __device__ __forceinline__ void direct_range(const float *__restrict__ x, uint32_t lo, uint32_t hi, Acc2 &a)
 {
     if (lo >= hi) return;
@@ -72,18 +57,24 @@ __device__ __forceinline__ void direct_range(const float *__restrict__ x, uint32
     if (threadIdx.x < lo4 - lo) acc1(a, x[lo + threadIdx.x]);
     if (threadIdx.x < hi - hi4) acc1(a, x[hi4 + threadIdx.x]);
     const float4 *q = reinterpret_cast<const float4 *>(x);
-    for (uint32_t i = (lo4 >> 2) + threadIdx.x; i < (hi4 >> 2); i += ASX_PREP_THREADS) {
-        const float4 v = q[i];
-        acc1(a, v.x); acc1(a, v.y); acc1(a, v.z); acc1(a, v.w);
+    const uint32_t end = hi4 >> 2;
+    uint32_t i = (lo4 >> 2) + threadIdx.x;
+    Acc2 b{ 0.0, 0.0 }, c{ 0.0, 0.0 }, d{ 0.0, 0.0 };
+    for (; i + 3u * ASX_PREP_THREADS < end; i += 4u * ASX_PREP_THREADS) {
+        const float4 v0 = q[i], v1 = q[i + ASX_PREP_THREADS], v2 = q[i + 2u * ASX_PREP_THREADS], v3 = q[i + 3u * ASX_PREP_THREADS];
+        acc4(a, v0); acc4(b, v1); acc4(c, v2); acc4(d, v3);
     }
+    for (; i < end; i += ASX_PREP_THREADS) acc4(a, q[i]);
+    a.s1 += (b.s1 + c.s1) + d.s1;
+    a.s2 += (b.s2 + c.s2) + d.s2;
 }
 
-// Window sums of one track over [lo, hi): whole bands from the band sums, the two edges from the samples.
+// This thread's share of the window sums of one track over [lo, hi): whole bands from the band sums, the two edges from the samples.
 //   band: [ntiles][nbands] {sum, sum of squares} as k_fwd_cols_r left them (every block its own run); a band = gs consecutive samples.
 //   The (tile, band) cells of the window are dealt to the threads in order -- consecutive lanes walk the bands of a tile --
 //   and added in float64: a fixed order.
-__device__ __forceinline__ Acc2 window_sums(const float *__restrict__ x, const float2 *__restrict__ band, uint32_t gs, int ntiles,
-                                            int nbands, uint32_t lo, uint32_t hi, double (*red)[ASX_PREP_THREADS / 64])
+__device__ __forceinline__ Acc2 window_share(const float *__restrict__ x, const float2 *__restrict__ band, uint32_t gs, int ntiles,
+                                             int nbands, uint32_t lo, uint32_t hi)
 {
     Acc2 a{ 0.0, 0.0 };
     const uint32_t ba = (lo + gs - 1) / gs, bb = hi / gs;
@@ -93,17 +84,44 @@ __device__ __forceinline__ Acc2 window_sums(const float *__restrict__ x, const f
         const uint32_t w = bb - ba, cells = w * (uint32_t)ntiles;
         const uint32_t dq = ASX_PREP_THREADS / w, dr = ASX_PREP_THREADS - dq * w; // one step of the cell index, as (tiles, bands)
         uint32_t t = threadIdx.x / w, b = threadIdx.x - t * w;
-        for (uint32_t i = threadIdx.x; i < cells; i += ASX_PREP_THREADS) {
-            const float2 v = band[(size_t)t * nbands + ba + b];
-            a.s1 += (double)v.x;
-            a.s2 += (double)v.y;
-            t += dq; b += dr;
+        Acc2 e{ 0.0, 0.0 };
+        uint32_t i = threadIdx.x;
+        for (; i + ASX_PREP_THREADS < cells; i += 2u * ASX_PREP_THREADS) { // two cells in flight
+            uint32_t t2 = t + dq, b2 = b + dr;
+            if (b2 >= w) { b2 -= w; t2++; }
+            const float2 v = band[(size_t)t * nbands + ba + b], v2 = band[(size_t)t2 * nbands + ba + b2];
+            a.s1 += (double)v.x; a.s2 += (double)v.y;
+            e.s1 += (double)v2.x; e.s2 += (double)v2.y;
+            t = t2 + dq; b = b2 + dr;
             if (b >= w) { b -= w; t++; }
         }
+        if (i < cells) {
+            const float2 v = band[(size_t)t * nbands + ba + b];
+            a.s1 += (double)v.x; a.s2 += (double)v.y;
+        }
+        a.s1 += e.s1; a.s2 += e.s2;
     } else {
         direct_range(x, lo, hi, a);
     }
-    return block_sum2(a, red);
+    return a;
+}
+
+// block-wide sums of four numbers, fixed order (lane tree, then waves in order); valid in every thread
+__device__ __forceinline__ void block_sum4(double (&v)[4], double (*red)[ASX_PREP_THREADS / 64])
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] += __shfl_xor(v[k], off, 64);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0)
+        for (int k = 0; k < 4; k++) red[k][wave] = v[k];
+    __syncthreads();
+    for (int k = 0; k < 4; k++) {
+        double t = red[k][0];
+        for (int w = 1; w < ASX_PREP_THREADS / 64; w++) t += red[k][w];
+        v[k] = t;
+    }
 }
 
 } // namespace
@@ -113,7 +131,7 @@ __global__ __launch_bounds__(ASX_PREP_THREADS) void k_pearson_prep(const AsxDev 
                                                                     const float *__restrict__ smp, AsxPeakWs W, AsxSpecWs S,
                                                                     const AsxSeg *__restrict__ seg)
 {
-    __shared__ double red[2][ASX_PREP_THREADS / 64];
+    __shared__ double red[4][ASX_PREP_THREADS / 64];
     __shared__ double s_exact;
     __shared__ int s_have_exact;
     const size_t pair = blockIdx.x;
@@ -139,9 +157,11 @@ __global__ __launch_bounds__(ASX_PREP_THREADS) void k_pearson_prep(const AsxDev 
         const float *x = src + pair * (size_t)(2u * N), *y = smp + pair * (size_t)N;
         const int ntiles = Pp->ntiles;
         const float2 *bx = W.band + (size_t)pair * 2 * ntiles * nbands, *by = bx + (size_t)ntiles * nbands;
-        const Acc2 ax = window_sums(x, bx, gs, ntiles, nbands, s.src_off, s.src_off + s.len, red);
-        const Acc2 ay = window_sums(y, by, gs, ntiles, nbands, s.smp_off, s.smp_off + s.len, red);
-        Sx = ax.s1; Sxx = ax.s2; Sy = ay.s1; Syy = ay.s2;
+        const Acc2 ax = window_share(x, bx, gs, ntiles, nbands, s.src_off, s.src_off + s.len);
+        const Acc2 ay = window_share(y, by, gs, ntiles, nbands, s.smp_off, s.smp_off + s.len);
+        double v[4] = { ax.s1, ax.s2, ay.s1, ay.s2 };
+        block_sum4(v, red);
+        Sx = v[0]; Sxx = v[1]; Sy = v[2]; Syy = v[3];
         // r[peak] in the plain-sum scale and the bound on its error
         double rb;
         if (s_have_exact) { r = s_exact; rb = 0.0; }
