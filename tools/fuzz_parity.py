@@ -19,7 +19,7 @@ L.cross_correlation.restype = ctypes.c_int
 L.cross_correlation.argtypes = [dp, dp, ctypes.c_size_t, ctypes.POINTER(ctypes.c_long), dp]
 PROD = [144000, 288000, 480000] if os.environ.get("FUZZ_BIG") == "1" else [144000, 288000]
 if os.environ.get("FUZZ_HUGE") == "1": PROD = [720000, 960000, 1440000]
-t0 = time.time(); trials = checked = 0; layouts = {}
+t0 = time.time(); trials = checked = 0; layouts = {}; modes = [0, 0, 0]; worst = 0.0
 while time.time() - t0 < budget:
     r = rng.uniform()
     if os.environ.get("FUZZ_BIG") == "1": r *= 0.5   # FUZZ_BIG=1: only the production and the large lengths
@@ -64,6 +64,7 @@ while time.time() - t0 < budget:
         dc = d_coef.cpu().numpy()
         assert all((a == b) or (a != a and b != b) for a, b in zip(dc, np.asarray(coef))), ("dev coef", trials, n, kind)
         layouts[plan.layout] = layouts.get(plan.layout, 0) + 1
+        modes = [a + b for a, b in zip(modes, plan.pearson_modes())]   # both entry points count (round 5: the spectral Pearson form)
     for b in range(batch):
         o_ret, o_lag, o_coef, o_r, margin = oracle.cross_correlation(s32[b], t32[b], want_results=True)
         if margin < 1.0 + (1e-11 if kind == 6 else 1e-9) and not silent:
@@ -72,6 +73,7 @@ while time.time() - t0 < budget:
         assert int(lag[b]) == o_lag, ("lag", trials, n, kind, b, int(lag[b]), o_lag, margin)
         if o_ret == 0:
             assert abs(float(coef[b]) - o_coef) < 1e-5, ("coef", trials, n, kind, b, float(coef[b]), o_coef)
+            worst = max(worst, abs(float(coef[b]) - o_coef))
         checked += 1
     if trials % 7 == 0:   # the reference API on the first pair, float64 inputs with low bits float32 cannot hold
         s64 = s32[0].astype(np.float64) * (1.0 + 1e-9); t64 = t32[0].astype(np.float64) * (1.0 - 3e-10)
@@ -84,4 +86,6 @@ while time.time() - t0 < budget:
                 assert abs(cf.value - o_coef) < 1e-5, ("f64 coef", trials, n, cf.value, o_coef)
             checked += 1
     trials += 1
-print("fuzz ok: %d problems, %d pairs checked against the oracle in %.0f s; plans by decomposition: %s" % (trials, checked, time.time() - t0, layouts))
+print("fuzz ok: %d problems, %d pairs checked against the oracle in %.0f s; plans by decomposition: %s; pairs by Pearson form "
+      "(spectral, + wrap-around correction, direct under the spectral setting) %s; worst |coefficient - oracle| %.3g"
+      % (trials, checked, time.time() - t0, layouts, modes, worst))
