@@ -201,7 +201,10 @@ int asx_xcorr_batch_multi_dev(asx_comm *comm, const float *const *d_source, cons
 
 /* Debug/parity aid: run ONE device-resident pair and also return the raw
  * correlation r[0..2N) (device pointer, 2N floats; scaled by F/(2N) relative
- * to the reference when the length had to be embedded). */
+ * to the reference when the length had to be embedded).  Like every entry point it
+ * takes the second look at a pair whose near-tie list overflowed (exact mode, the
+ * default) or marks it with ret = 1 (asx_plan_set_exact(plan, 0)), and leaves nothing
+ * on the plan's overflow list either way; the coefficient is the direct form's. */
 int asx_xcorr_debug_r_dev(asx_plan *plan, const float *d_source, const float *d_sample,
                           float *d_r, int64_t *d_lag, double *d_coef, int32_t *d_ret,
                           void *stream);
