@@ -146,7 +146,7 @@ def cpu_baseline(sample_len, point_seconds=3.0, sweeps=3):
     >= `point_seconds` of wall time per sweep, `sweeps` sweeps; a point's rate is the MEDIAN of its sweeps, `value` the
     best point, `spread` (max - min) / median of that point over the sweeps (round 4's points ran 0.4-1.8 s
     once, and moved 1.6x between rounds).  Backend: FFTW3 if libfftw3.so.3 can be dlopen()ed here, else the oracle's own
-    DFT (labelled).  About 30-40 s in all."""
+    DFT (labelled).  About 45 s in all."""
     import oracle
     cores, usable = os.cpu_count() or 1, cpu_quota()
     backend = oracle.baseline_backend()
@@ -180,7 +180,8 @@ def cpu_baseline(sample_len, point_seconds=3.0, sweeps=3):
     runs = {wk: [] for wk in cands}                                     # every point ran 10-30 % low without it)
     for _ in range(sweeps):
         for wk in cands:
-            rate, dt, done = _throughput(sample_len, pairs, wk, rounds)
+            # more workers than usable CPUs share them: fewer calls each, the same >= point_seconds of wall time per point
+            rate, dt, done = _throughput(sample_len, pairs, wk, max(2, rounds * min(wk, usable) // wk))
             runs[wk].append({"calls": done, "seconds": round(dt, 3), "per_s": round(rate, 2)})
     points = []
     for wk in cands:
