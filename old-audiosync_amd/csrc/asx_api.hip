@@ -820,7 +820,7 @@ extern "C" int asx_xcorr_batch_f32_dev(asx_plan *p, const float *d_source, const
     if (!dg.ok) return fail("cannot select device %d", p->device);
     hipStream_t s = stream ? (hipStream_t)stream : p->stream;
     const size_t N = p->host.N;
-    if (p->tune_placement && !p->placement_done && p->nlanes == 1 && batch >= std::min<size_t>(p->group, 8) &&
+    if (p->tune_placement && !p->placement_done && batch >= std::min<size_t>(p->group, 8) && // (lane 0's workspaces; a second lane keeps its own)
         tune_placement(p, d_source, d_sample, std::min(batch, p->group), s))
         return -1;
     prof_begin_call(p);
