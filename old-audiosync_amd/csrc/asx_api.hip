@@ -631,8 +631,8 @@ static int run_group(asx_plan *p, const float *d_src, const float *d_smp, const 
     asx_launch_inv_cols(P, q, tk, d_r, (int)g, s);
     if (prof_mark(p, s, e0 + 3)) return -1;
     asx_launch_finalize(P, fin, W.seg, (int)g, s, pair_base);
-    if (sizeof(TIn) == sizeof(float))
-        asx_launch_refine_f32(P, (const float *)p_src, (const float *)p_smp, W.pk, W.seg, (int)g, s);
+    if (sizeof(TIn) == sizeof(float)) // (the spectral form's first kernel applies the rule to the exact values itself: one launch less)
+        asx_launch_refine_f32(P, (const float *)p_src, (const float *)p_smp, W.pk, W.seg, (int)g, s, ASX_DOT_BLOCKS, !spectral);
     else
         asx_launch_refine_f64(P, (const double *)p_src, (const double *)p_smp, W.pk, W.seg, (int)g, s);
     if (prof_mark(p, s, e0 + 4)) return -1;

@@ -159,7 +159,8 @@ bool asx_rlayout_available(const AsxDev &P); // all three kernels compiled in fo
 int asx_rlayout_band_rows(const AsxDev &P);
 void asx_launch_finalize(const AsxDev &P, const AsxPeakWs &W, AsxSeg *seg, int npairs, hipStream_t s, uint32_t pair_base = 0);
 void asx_launch_refine_f32(const AsxDev &P, const float *src, const float *smp, const AsxPeakWs &W,
-                           AsxSeg *seg, int npairs, hipStream_t s, int dot_blocks = ASX_DOT_BLOCKS);
+                           AsxSeg *seg, int npairs, hipStream_t s, int dot_blocks = ASX_DOT_BLOCKS, bool pick = true);
+                           // pick = false: the exact values only; the caller's next kernel applies the rule (k_pearson_prep)
 void asx_launch_refine_f64(const AsxDev &P, const double *src, const double *smp, const AsxPeakWs &W,
                            AsxSeg *seg, int npairs, hipStream_t s, int dot_blocks = ASX_DOT_BLOCKS);
 void asx_launch_pearson_f32(const float *src, const float *smp, size_t src_pitch, size_t smp_pitch,
@@ -173,7 +174,7 @@ void asx_launch_pearson_partial_f32(const float *src, const float *smp, size_t s
                                     uint32_t basis_len, const AsxSeg *seg, double *psums, int npairs, hipStream_t s);
 // pearson_spectral.hip: float32 inputs, real-column plans (W.band and W.tile_peak filled by this group's transform kernels)
 void asx_launch_pearson_spectral_f32(const AsxDev &P, const float *src, const float *smp, const AsxPeakWs &W, const AsxSpecWs &S,
-                                     const AsxSeg *seg, double *psums, int64_t *lag, double *coef, int32_t *ret, int npairs,
+                                     AsxSeg *seg, double *psums, int64_t *lag, double *coef, int32_t *ret, int npairs,
                                      hipStream_t s);
 void asx_launch_results_to_ms(const int64_t *lag, const double *coef, const int32_t *ret, size_t batch,
                               double min_confidence, double sample_rate, int64_t *lag_ms, int32_t *accept,

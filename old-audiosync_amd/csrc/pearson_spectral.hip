@@ -126,28 +126,63 @@ __device__ __forceinline__ void block_sum4(double (&v)[4], double (*red)[ASX_PRE
 
 } // namespace
 
-// grid (npairs), ASX_PREP_THREADS.  Decides each pair's mode, leaves its window sums and r[peak] in pre[], its work list in seg2[].
+// grid (npairs), ASX_PREP_THREADS.  Picks the winner among the re-evaluated near-ties (if any), decides each pair's mode, leaves its window sums and r[peak] in pre[], its work list in seg2[].
 __global__ __launch_bounds__(ASX_PREP_THREADS) void k_pearson_prep(const AsxDev *__restrict__ Pp, const float *__restrict__ src,
                                                                     const float *__restrict__ smp, AsxPeakWs W, AsxSpecWs S,
-                                                                    const AsxSeg *__restrict__ seg)
+                                                                    AsxSeg *__restrict__ seg)
 {
     __shared__ double red[4][ASX_PREP_THREADS / 64];
     __shared__ double s_exact;
     __shared__ int s_have_exact;
+    __shared__ double rkey[ASX_PREP_THREADS / 64], rval[ASX_PREP_THREADS / 64];
+    __shared__ uint32_t ridx[ASX_PREP_THREADS / 64];
+    __shared__ AsxSeg s_seg;
     const size_t pair = blockIdx.x;
     const uint32_t N = Pp->N;
     const int M2 = Pp->M2, nbands = Pp->nbands;
     const uint32_t gs = (uint32_t)Pp->band_rows * (uint32_t)M2;
-    const AsxSeg s = seg[pair];
     double *pre = S.pre + pair * ASX_PRE_DOUBLES;
     const asx_peak_t best = W.pairmax[pair];
-    // the exact r[peak] when the pair's near-ties were re-evaluated (k_refine_dots / k_refine_pick): the entry of the winner
-    if (threadIdx.x == 0) s_have_exact = 0;
-    __syncthreads();
+    // ---- k_refine_pick's part (xcorr_kernels.hip; this kernel stands in for it in the spectral form: one launch less): the
+    // reference's max_abs_index rule (src/cross_correlation.c:52-67) on the exact values of the re-evaluated near-ties --
+    // key(0) = r[0] signed, key(i) = |r[i]|, largest key, smallest lag among equal keys, a NaN never wins unless at lag 0 --
+    // and, kept here, the winner's exact SIGNED value: the cross term of the coefficient
     const uint32_t nref = W.refine_n[pair];
-    for (uint32_t i = threadIdx.x; i < nref; i += ASX_PREP_THREADS)
-        if (W.refine_idx[pair * (size_t)W.cap + i] == s.peak) { s_exact = W.refine_val[pair * (size_t)W.cap + i]; s_have_exact = 1; }
+    if (nref >= 2u) { // block-uniform
+        double bk = -INFINITY, bv = 0.0;
+        uint32_t bi = 0xFFFFFFFFu;
+        for (uint32_t i = threadIdx.x; i < nref; i += ASX_PREP_THREADS) {
+            const uint32_t idx = W.refine_idx[pair * (size_t)W.cap + i];
+            const double v = W.refine_val[pair * (size_t)W.cap + i];
+            double key;
+            if (idx == 0u) key = (v != v) ? (double)INFINITY : v + 0.0;
+            else { key = fabs(v); if (key != key) key = -(double)INFINITY; }
+            if (key > bk || (key == bk && idx < bi)) { bk = key; bi = idx; bv = v; }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const double ok = __shfl_xor(bk, off, 64), ov = __shfl_xor(bv, off, 64);
+            const uint32_t oi = (uint32_t)__shfl_xor((int)bi, off, 64);
+            if (ok > bk || (ok == bk && oi < bi)) { bk = ok; bi = oi; bv = ov; }
+        }
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        if (lane == 0) { rkey[wave] = bk; ridx[wave] = bi; rval[wave] = bv; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < ASX_PREP_THREADS / 64; w++)
+                if (rkey[w] > bk || (rkey[w] == bk && ridx[w] < bi)) { bk = rkey[w]; bi = ridx[w]; bv = rval[w]; }
+            AsxSeg sg = seg[pair];
+            if (bi != 0xFFFFFFFFu) { sg = make_seg(bi, N); seg[pair] = sg; }
+            s_seg = sg;
+            s_exact = bv;
+            s_have_exact = bi != 0xFFFFFFFFu;
+        }
+    } else if (threadIdx.x == 0) {
+        s_seg = seg[pair];
+        s_have_exact = 0;
+    }
     __syncthreads();
+    const AsxSeg s = s_seg;
     // A pair the transforms had nothing to say about (silent or NaN track: no maximum), an empty segment, or a lag that is still
     // the float32 placeholder of an overflowed list (the second look redoes it): the direct reduction, whatever it yields.
     const bool direct = best == 0 || s.len == 0 || (s.flags & ASX_SEG_INEXACT) != 0;
@@ -232,7 +267,7 @@ __global__ __launch_bounds__(64) void k_pearson_final_spec(const AsxSeg *__restr
 }
 
 void asx_launch_pearson_spectral_f32(const AsxDev &P, const float *src, const float *smp, const AsxPeakWs &W, const AsxSpecWs &S,
-                                     const AsxSeg *seg, double *psums, int64_t *lag, double *coef, int32_t *ret, int npairs,
+                                     AsxSeg *seg, double *psums, int64_t *lag, double *coef, int32_t *ret, int npairs,
                                      hipStream_t s)
 {
     hipLaunchKernelGGL(k_pearson_prep, dim3(npairs), dim3(ASX_PREP_THREADS), 0, s, P.self_dev, src, smp, W, S, seg);

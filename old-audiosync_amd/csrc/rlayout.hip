@@ -560,8 +560,8 @@ __global__ __launch_bounds__(NT, 4) void k_inv_cols_r(const RArgs P, const float
     {
         // Stagger: the blocks that share a CU run the same program -- a load phase (the tile's rows), then compute phases of about
         // the same length -- and, started together, stay in step: both wait for memory, then both compute.  The blocks of the FIRST
-        // generation start a fraction of a block's life apart, by their position in the launch order (consecutive blocks land on
-        // the same CU more often than not); later generations inherit the offset.  0.370 -> 0.349 ms at 600 rows, -3 .. -6 % at 400 (rows and
+        // generation start half a block's life apart, by the parity of their position in the launch order (the split that measured
+        // best); later generations inherit the offset.  0.370 -> 0.349 ms at 600 rows, -3 .. -6 % at 400 (rows and
         // forward columns: nothing, profiles/r5_experiments/05_*).  Speed only.
         constexpr bool TWO_PER_CU = (size_t)M1 * T * 8 > 40 * 1024; // 600- and 400-row tiles; four blocks of 300 rows: measured 1.5 % slower
         const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y;

@@ -1476,10 +1476,10 @@ void asx_launch_finalize(const AsxDev &P, const AsxPeakWs &W, AsxSeg *seg, int n
 }
 
 void asx_launch_refine_f32(const AsxDev &P, const float *src, const float *smp, const AsxPeakWs &W,
-                           AsxSeg *seg, int npairs, hipStream_t s, int dot_blocks)
+                           AsxSeg *seg, int npairs, hipStream_t s, int dot_blocks, bool pick)
 {
     hipLaunchKernelGGL(k_refine_dots<float>, dim3(dot_blocks, npairs), dim3(ASX_THREADS), 0, s, P.self_dev, src, smp, W);
-    hipLaunchKernelGGL(k_refine_pick, dim3(npairs), dim3(ASX_THREADS), 0, s, P.self_dev, W, seg);
+    if (pick) hipLaunchKernelGGL(k_refine_pick, dim3(npairs), dim3(ASX_THREADS), 0, s, P.self_dev, W, seg);
 }
 
 void asx_launch_refine_f64(const AsxDev &P, const double *src, const double *smp, const AsxPeakWs &W,
