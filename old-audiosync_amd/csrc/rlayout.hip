@@ -117,6 +117,31 @@ __host__ __device__ constexpr int rcol_rows_per_group(int m1, int nt, int t) { r
 #else
 #define RWS_PAIR(pair) (pair)
 #endif
+// Non-temporal accesses for everything these kernels touch exactly once between its producer and its consumer: C written by
+// k_fwd_cols_r (2) and read by k_rows_r (4), Q written by k_rows_r (8) and read by k_inv_cols_r (1).  All four together,
+// same box, six alternating rounds: forward columns 1.019 -> 0.992 ms, rows 0.944 -> 0.926, inverse columns 0.325 -> 0.306,
+// 51.6 -> 53.1 k/s (profiles/r5_experiments/10_*; the row LOADS alone slow the inverse kernel by 10 %: all or none).  The inputs stay
+// temporal: the two tiles of a 128-byte input line meet in one XCD's L2 (rcol_tile_of_block); non-temporal, 0.987 -> 1.000 ms.
+#ifndef ASX_RNT
+#define ASX_RNT 15
+#endif
+typedef float asx_f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld_f4(const void *p, bool nt)
+{
+    if (nt) { const asx_f4v v = __builtin_nontemporal_load(reinterpret_cast<const asx_f4v *>(p)); return make_float4(v.x, v.y, v.z, v.w); }
+    return *reinterpret_cast<const float4 *>(p);
+}
+__device__ __forceinline__ void st_f4(void *p, float4 v, bool nt)
+{
+    if (nt) { asx_f4v w; w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w; __builtin_nontemporal_store(w, reinterpret_cast<asx_f4v *>(p)); }
+    else *reinterpret_cast<float4 *>(p) = v;
+}
+typedef float asx_f2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void st_f2(float2 *p, float2 v, bool nt)
+{
+    if (nt) { asx_f2v w; w.x = v.x; w.y = v.y; __builtin_nontemporal_store(w, reinterpret_cast<asx_f2v *>(p)); }
+    else *p = v;
+}
 #ifndef ASX_ROWS2_SCHED
 #define ASX_ROWS2_SCHED 12, 10, 10
 #endif
@@ -192,11 +217,11 @@ __global__ __launch_bounds__(TWO ? 2 * NT : NT, ASX_ROWSR_WAVES) void k_rows_r(c
         static_for<0, WSTEPS>([&](auto I) __attribute__((always_inline)) {
             const int q = tid + decltype(I)::value * NTB;
             if (q < HALF) {
-                lx[I] = *reinterpret_cast<const float4 *>(gx + 2 * q);
-                ly[I] = *reinterpret_cast<const float4 *>(gy + 2 * q);
+                lx[I] = ld_f4(gx + 2 * q, ASX_RNT & 4);
+                ly[I] = ld_f4(gy + 2 * q, ASX_RNT & 4);
                 if constexpr (TWO) {
-                    lx2[I] = *reinterpret_cast<const float4 *>(gx + NS + 2 * q);
-                    ly2[I] = *reinterpret_cast<const float4 *>(gy + NS + 2 * q);
+                    lx2[I] = ld_f4(gx + NS + 2 * q, ASX_RNT & 4);
+                    ly2[I] = ld_f4(gy + NS + 2 * q, ASX_RNT & 4);
                 }
             }
         });
@@ -324,7 +349,7 @@ __global__ __launch_bounds__(TWO ? 2 * NT : NT, ASX_ROWSR_WAVES) void k_rows_r(c
             static_for<0, R0>([&](auto T) __attribute__((always_inline)) {
                 constexpr int t = decltype(T)::value;
                 const Cx1 y = mulwc(v[t], t == 0 ? fb : cmul(fb, leg[t]));
-                go[j + t * Q0] = make_float2(y.re, y.im);
+                st_f2(go + j + t * Q0, make_float2(y.re, y.im), ASX_RNT & 8);
             });
         }
     } else {
@@ -354,8 +379,8 @@ __global__ __launch_bounds__(TWO ? 2 * NT : NT, ASX_ROWSR_WAVES) void k_rows_r(c
                 const float2 lg = leg[t];
                 const Cx1 y = mulwc(A + Bw, t == 0 ? fa : cmul(fa, lg));
                 const Cx1 z = mulwc(A - Bw, t == 0 ? fbh : cmul(fbh, lg));
-                go[j + t * Q0] = make_float2(y.re, y.im);
-                go[NS + j + t * Q0] = make_float2(z.re, z.im);
+                st_f2(go + j + t * Q0, make_float2(y.re, y.im), ASX_RNT & 8);
+                st_f2(go + NS + j + t * Q0, make_float2(z.re, z.im), ASX_RNT & 8);
             });
         }
     }
@@ -495,8 +520,8 @@ __global__ __launch_bounds__(NT, 4) void k_fwd_cols_r(const RArgs P, const float
         Bfly<RL, false>::run(zb);
         const int cg = 2 * g;
         auto row = [&](int u, Cx2 c, bool conj) __attribute__((always_inline)) {
-            *reinterpret_cast<float4 *>(out + (size_t)u * M2 + c0 + cg) = conj ? make_float4(c.re.x, -c.im.x, c.re.y, -c.im.y)
-                                                                           : make_float4(c.re.x, c.im.x, c.re.y, c.im.y);
+            st_f4(out + (size_t)u * M2 + c0 + cg, conj ? make_float4(c.re.x, -c.im.x, c.re.y, -c.im.y)
+                                                       : make_float4(c.re.x, c.im.x, c.re.y, c.im.y), ASX_RNT & 2);
         };
         if (v != 0) {
             const float2 wu = tw_F(P, (uint32_t)ub * (uint32_t)M2); // w_{2 M1}^u_b = w_F^(u_b M2)
@@ -602,8 +627,8 @@ __global__ __launch_bounds__(NT, 4) void k_inv_cols_r(const RArgs P, const float
         Cx2 A[RL], B[RL];
         static_for<0, RL>([&](auto TT) __attribute__((always_inline)) {
             constexpr int t = decltype(TT)::value;
-            const float4 x = *reinterpret_cast<const float4 *>(ca + (size_t)(t * MB) * M2);
-            const float4 y = *reinterpret_cast<const float4 *>(cb + (size_t)(t * MB) * M2);
+            const float4 x = ld_f4(ca + (size_t)(t * MB) * M2, ASX_RNT & 1);
+            const float4 y = ld_f4(cb + (size_t)(t * MB) * M2, ASX_RNT & 1);
             A[t] = Cx2{ v2f{ x.x, x.z }, v2f{ x.y, x.w } };
             B[t] = Cx2{ v2f{ y.x, y.z }, v2f{ y.y, y.w } };
         });
@@ -622,7 +647,7 @@ __global__ __launch_bounds__(NT, 4) void k_inv_cols_r(const RArgs P, const float
             });
         } else {
             // u_b = 0: Q[MB t] pairs with Q[MB (RL - t)], t = 0 with the extra row M1; u_b = MB/2: within the butterfly
-            const float4 xm = *reinterpret_cast<const float4 *>(in + (size_t)M1 * M2 + c0 + 2 * g);
+            const float4 xm = ld_f4(in + (size_t)M1 * M2 + c0 + 2 * g, ASX_RNT & 1);
             const Cx2 QM = Cx2{ v2f{ xm.x, xm.z }, v2f{ xm.y, xm.w } };
             static_for<0, RL>([&](auto TT) __attribute__((always_inline)) {
                 constexpr int t = decltype(TT)::value;
