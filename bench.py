@@ -351,7 +351,17 @@ def capi_leg_guarded(ngpus, steps, in_process):
     GPU (no multi-GPU node was available to any round), and a fault in it must not take the headline line down with it"""
     try:
         if in_process:
-            return capi_leg(ngpus, steps)
+            # RCCL prints a version banner on STDOUT when the library's communicator comes up; the contract is ONE JSON line
+            # there, so file descriptor 1 points at stderr for the length of this leg (as around the process group's start-up)
+            sys.stdout.flush()
+            saved_stdout = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                return capi_leg(ngpus, steps)
+            finally:
+                sys.stdout.flush()
+                os.dup2(saved_stdout, 1)
+                os.close(saved_stdout)
         cmd = [sys.executable, os.path.abspath(__file__), "--mode", "capi", "--gpus", str(ngpus), "--steps4", str(steps)]
         p = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
         lines = [l for l in p.stdout.splitlines() if l.startswith("{")]

@@ -39,3 +39,25 @@ def test_audiosync_run_gives_up_on_noise(built):
     out = subprocess.run([os.path.join(built, "run_feed"), "5000", "2.0"], capture_output=True, text=True, timeout=600)
     ret, lag_ms, status = out.stdout.split()
     assert int(ret) == -1 and status == "idle"
+
+
+def test_bench_prints_exactly_one_json_line_on_stdout():
+    """the driver's contract: `python bench.py --gpus 1 --steps K --warmup W` -> ONE JSON line on stdout, whatever the libraries
+    underneath print when they come up (RCCL's version banner of the config4_capi leg went to stdout once, round 5)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--precondition", "2",
+                        "--no-cpu", "--steps4", "1"], capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines[:-1]
+    d = json.loads(lines[0])
+    assert d["results_ok"] and d["config4"]["results_ok"] and d["config4_capi"].get("results_ok") is True, d.get("config4_capi")
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline"):
+        assert key in d, key
+    assert "cpu_baseline" not in d          # --no-cpu
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
