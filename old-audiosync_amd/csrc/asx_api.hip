@@ -631,10 +631,14 @@ static int run_group(asx_plan *p, const float *d_src, const float *d_smp, const 
     asx_launch_inv_cols(P, q, tk, d_r, (int)g, s);
     if (prof_mark(p, s, e0 + 3)) return -1;
     asx_launch_finalize(P, fin, W.seg, (int)g, s, pair_base);
+    // Blocks per pair of the exact re-evaluation: a candidate is one whole block's work whatever the grid, so the count only
+    // sets how many candidates of a pair are in flight.  Nearly every block of a batch finds no candidate and exits: with 1024
+    // pairs, 128 blocks each were 131 072 empty blocks, 25 us of a 2 ms step.
+    const int dot_blocks = (int)std::min<size_t>(ASX_DOT_BLOCKS, std::max<size_t>(8, 16384 / g));
     if (sizeof(TIn) == sizeof(float)) // (the spectral form's first kernel applies the rule to the exact values itself: one launch less)
-        asx_launch_refine_f32(P, (const float *)p_src, (const float *)p_smp, W.pk, W.seg, (int)g, s, ASX_DOT_BLOCKS, !spectral);
+        asx_launch_refine_f32(P, (const float *)p_src, (const float *)p_smp, W.pk, W.seg, (int)g, s, dot_blocks, !spectral);
     else
-        asx_launch_refine_f64(P, (const double *)p_src, (const double *)p_smp, W.pk, W.seg, (int)g, s);
+        asx_launch_refine_f64(P, (const double *)p_src, (const double *)p_smp, W.pk, W.seg, (int)g, s, dot_blocks);
     if (prof_mark(p, s, e0 + 4)) return -1;
     if (spectral)
         asx_launch_pearson_spectral_f32(P, (const float *)p_src, (const float *)p_smp, tk, W.spec, W.seg, W.psums, d_lag, d_coef,

@@ -27,7 +27,6 @@
 #include "asx_internal.h"
 #include "xcorr_dev.h"
 
-#define ASX_PREP_THREADS 1024
 
 namespace {
 
@@ -46,12 +45,12 @@ __device__ __forceinline__ void acc4(Acc2 &a, float4 v) { acc1(a, v.x); acc1(a, 
 // sum and sum of squares of track[lo .. hi) (float64 from the float32 samples), this thread's share: 16-byte loads over the
 // aligned middle (the track starts on a 16-byte boundary: 2N and N are multiples of four), the ragged ends by single lanes.
 // Four loads in flight per thread, each into its own accumulator (a fixed order all the same: the four are added at the end).
-__device__ __forceinline__ void direct_range(const float *__restrict__ x, uint32_t lo, uint32_t hi, Acc2 &a)
+template <int NTP> __device__ __forceinline__ void direct_range(const float *__restrict__ x, uint32_t lo, uint32_t hi, Acc2 &a)
 {
     if (lo >= hi) return;
     const uint32_t lo4 = (lo + 3u) & ~3u, hi4 = hi & ~3u;
     if (lo4 >= hi4) { // no aligned quad inside
-        for (uint32_t i = lo + threadIdx.x; i < hi; i += ASX_PREP_THREADS) acc1(a, x[i]);
+        for (uint32_t i = lo + threadIdx.x; i < hi; i += NTP) acc1(a, x[i]);
         return;
     }
     if (threadIdx.x < lo4 - lo) acc1(a, x[lo + threadIdx.x]);
@@ -60,11 +59,11 @@ __device__ __forceinline__ void direct_range(const float *__restrict__ x, uint32
     const uint32_t end = hi4 >> 2;
     uint32_t i = (lo4 >> 2) + threadIdx.x;
     Acc2 b{ 0.0, 0.0 }, c{ 0.0, 0.0 }, d{ 0.0, 0.0 };
-    for (; i + 3u * ASX_PREP_THREADS < end; i += 4u * ASX_PREP_THREADS) {
-        const float4 v0 = q[i], v1 = q[i + ASX_PREP_THREADS], v2 = q[i + 2u * ASX_PREP_THREADS], v3 = q[i + 3u * ASX_PREP_THREADS];
+    for (; i + 3u * NTP < end; i += 4u * NTP) {
+        const float4 v0 = q[i], v1 = q[i + NTP], v2 = q[i + 2u * NTP], v3 = q[i + 3u * NTP];
         acc4(a, v0); acc4(b, v1); acc4(c, v2); acc4(d, v3);
     }
-    for (; i < end; i += ASX_PREP_THREADS) acc4(a, q[i]);
+    for (; i < end; i += NTP) acc4(a, q[i]);
     a.s1 += (b.s1 + c.s1) + d.s1;
     a.s2 += (b.s2 + c.s2) + d.s2;
 }
@@ -73,20 +72,20 @@ __device__ __forceinline__ void direct_range(const float *__restrict__ x, uint32
 //   band: [ntiles][nbands] {sum, sum of squares} as k_fwd_cols_r left them (every block its own run); a band = gs consecutive samples.
 //   The (tile, band) cells of the window are dealt to the threads in order -- consecutive lanes walk the bands of a tile --
 //   and added in float64: a fixed order.
-__device__ __forceinline__ Acc2 window_share(const float *__restrict__ x, const float2 *__restrict__ band, uint32_t gs, int ntiles,
+template <int NTP> __device__ __forceinline__ Acc2 window_share(const float *__restrict__ x, const float2 *__restrict__ band, uint32_t gs, int ntiles,
                                              int nbands, uint32_t lo, uint32_t hi)
 {
     Acc2 a{ 0.0, 0.0 };
     const uint32_t ba = (lo + gs - 1) / gs, bb = hi / gs;
     if (ba < bb) {
-        direct_range(x, lo, ba * gs, a);
-        direct_range(x, bb * gs, hi, a);
+        direct_range<NTP>(x, lo, ba * gs, a);
+        direct_range<NTP>(x, bb * gs, hi, a);
         const uint32_t w = bb - ba, cells = w * (uint32_t)ntiles;
-        const uint32_t dq = ASX_PREP_THREADS / w, dr = ASX_PREP_THREADS - dq * w; // one step of the cell index, as (tiles, bands)
+        const uint32_t dq = NTP / w, dr = NTP - dq * w; // one step of the cell index, as (tiles, bands)
         uint32_t t = threadIdx.x / w, b = threadIdx.x - t * w;
         Acc2 e{ 0.0, 0.0 };
         uint32_t i = threadIdx.x;
-        for (; i + ASX_PREP_THREADS < cells; i += 2u * ASX_PREP_THREADS) { // two cells in flight
+        for (; i + NTP < cells; i += 2u * NTP) { // two cells in flight
             uint32_t t2 = t + dq, b2 = b + dr;
             if (b2 >= w) { b2 -= w; t2++; }
             const float2 v = band[(size_t)t * nbands + ba + b], v2 = band[(size_t)t2 * nbands + ba + b2];
@@ -101,13 +100,13 @@ __device__ __forceinline__ Acc2 window_share(const float *__restrict__ x, const 
         }
         a.s1 += e.s1; a.s2 += e.s2;
     } else {
-        direct_range(x, lo, hi, a);
+        direct_range<NTP>(x, lo, hi, a);
     }
     return a;
 }
 
 // block-wide sums of four numbers, fixed order (lane tree, then waves in order); valid in every thread
-__device__ __forceinline__ void block_sum4(double (&v)[4], double (*red)[ASX_PREP_THREADS / 64])
+template <int NTP> __device__ __forceinline__ void block_sum4(double (&v)[4], double (*red)[NTP / 64])
 {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1)
@@ -119,23 +118,24 @@ __device__ __forceinline__ void block_sum4(double (&v)[4], double (*red)[ASX_PRE
     __syncthreads();
     for (int k = 0; k < 4; k++) {
         double t = red[k][0];
-        for (int w = 1; w < ASX_PREP_THREADS / 64; w++) t += red[k][w];
+        for (int w = 1; w < NTP / 64; w++) t += red[k][w];
         v[k] = t;
     }
 }
 
 } // namespace
 
-// grid (npairs), ASX_PREP_THREADS.  Picks the winner among the re-evaluated near-ties (if any), decides each pair's mode, leaves its window sums and r[peak] in pre[], its work list in seg2[].
-__global__ __launch_bounds__(ASX_PREP_THREADS) void k_pearson_prep(const AsxDev *__restrict__ Pp, const float *__restrict__ src,
+// grid (npairs), NTP threads (1024 for the long tracks -- up to 77 000 samples of band edges and 18 000 cells per pair -- 256 below:
+// 1024 pairs of N = 144 000 took 61 us with 1024-thread blocks, the sixteen-wave fold of a few thousand numbers).  Picks the winner among the re-evaluated near-ties (if any), decides each pair's mode, leaves its window sums and r[peak] in pre[], its work list in seg2[].
+template <int NTP> __global__ __launch_bounds__(NTP) void k_pearson_prep(const AsxDev *__restrict__ Pp, const float *__restrict__ src,
                                                                     const float *__restrict__ smp, AsxPeakWs W, AsxSpecWs S,
                                                                     AsxSeg *__restrict__ seg)
 {
-    __shared__ double red[4][ASX_PREP_THREADS / 64];
+    __shared__ double red[4][NTP / 64];
     __shared__ double s_exact;
     __shared__ int s_have_exact;
-    __shared__ double rkey[ASX_PREP_THREADS / 64], rval[ASX_PREP_THREADS / 64];
-    __shared__ uint32_t ridx[ASX_PREP_THREADS / 64];
+    __shared__ double rkey[NTP / 64], rval[NTP / 64];
+    __shared__ uint32_t ridx[NTP / 64];
     __shared__ AsxSeg s_seg;
     const size_t pair = blockIdx.x;
     const uint32_t N = Pp->N;
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(ASX_PREP_THREADS) void k_pearson_prep(const AsxDev 
     if (nref >= 2u) { // block-uniform
         double bk = -INFINITY, bv = 0.0;
         uint32_t bi = 0xFFFFFFFFu;
-        for (uint32_t i = threadIdx.x; i < nref; i += ASX_PREP_THREADS) {
+        for (uint32_t i = threadIdx.x; i < nref; i += NTP) {
             const uint32_t idx = W.refine_idx[pair * (size_t)W.cap + i];
             const double v = W.refine_val[pair * (size_t)W.cap + i];
             double key;
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(ASX_PREP_THREADS) void k_pearson_prep(const AsxDev 
         if (lane == 0) { rkey[wave] = bk; ridx[wave] = bi; rval[wave] = bv; }
         __syncthreads();
         if (threadIdx.x == 0) {
-            for (int w = 1; w < ASX_PREP_THREADS / 64; w++)
+            for (int w = 1; w < NTP / 64; w++)
                 if (rkey[w] > bk || (rkey[w] == bk && ridx[w] < bi)) { bk = rkey[w]; bi = ridx[w]; bv = rval[w]; }
             AsxSeg sg = seg[pair];
             if (bi != 0xFFFFFFFFu) { sg = make_seg(bi, N); seg[pair] = sg; }
@@ -192,10 +192,10 @@ __global__ __launch_bounds__(ASX_PREP_THREADS) void k_pearson_prep(const AsxDev 
         const float *x = src + pair * (size_t)(2u * N), *y = smp + pair * (size_t)N;
         const int ntiles = Pp->ntiles;
         const float2 *bx = W.band + (size_t)pair * 2 * ntiles * nbands, *by = bx + (size_t)ntiles * nbands;
-        const Acc2 ax = window_share(x, bx, gs, ntiles, nbands, s.src_off, s.src_off + s.len);
-        const Acc2 ay = window_share(y, by, gs, ntiles, nbands, s.smp_off, s.smp_off + s.len);
+        const Acc2 ax = window_share<NTP>(x, bx, gs, ntiles, nbands, s.src_off, s.src_off + s.len);
+        const Acc2 ay = window_share<NTP>(y, by, gs, ntiles, nbands, s.smp_off, s.smp_off + s.len);
         double v[4] = { ax.s1, ax.s2, ay.s1, ay.s2 };
-        block_sum4(v, red);
+        block_sum4<NTP>(v, red);
         Sx = v[0]; Sxx = v[1]; Sy = v[2]; Syy = v[3];
         // r[peak] in the plain-sum scale and the bound on its error
         double rb;
@@ -270,7 +270,10 @@ void asx_launch_pearson_spectral_f32(const AsxDev &P, const float *src, const fl
                                      AsxSeg *seg, double *psums, int64_t *lag, double *coef, int32_t *ret, int npairs,
                                      hipStream_t s)
 {
-    hipLaunchKernelGGL(k_pearson_prep, dim3(npairs), dim3(ASX_PREP_THREADS), 0, s, P.self_dev, src, smp, W, S, seg);
+    if ((size_t)P.band_rows * (size_t)P.M2 >= 16384)
+        hipLaunchKernelGGL(k_pearson_prep<1024>, dim3(npairs), dim3(1024), 0, s, P.self_dev, src, smp, W, S, seg);
+    else
+        hipLaunchKernelGGL(k_pearson_prep<256>, dim3(npairs), dim3(256), 0, s, P.self_dev, src, smp, W, S, seg);
     asx_launch_pearson_partial_f32(src, smp, 2 * (size_t)P.N, P.N, P.N, S.seg2, psums, npairs, s);
     hipLaunchKernelGGL(k_pearson_final_spec, dim3(npairs), dim3(64), 0, s, seg, psums, asx_pearson_blocks(P.N), S.pre, lag, coef, ret);
 }
