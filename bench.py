@@ -588,12 +588,16 @@ def run_rank(args, cpu=None):
             warm = torch.zeros(1, device=torch.device("cuda", local_rank))
             dist.all_reduce(warm)
             torch.cuda.synchronize()
+            # a CPU-side group for waits that must not occupy the GPUs (the ranks idle while rank 0 runs the config4_capi leg:
+            # inside an RCCL barrier they would spin in a kernel on the very devices that leg uses)
+            cpu_group = dist.new_group(backend="gloo")
         finally:
             sys.stdout.flush()
             os.dup2(saved_stdout, 1)
             os.close(saved_stdout)
     else:
         torch.cuda.set_device(0)
+        cpu_group = None
     dev = torch.device("cuda", torch.cuda.current_device())
     stream = torch.cuda.Stream(dev)          # explicit: the library and the collective share THIS stream
     line = None
@@ -636,9 +640,12 @@ def run_rank(args, cpu=None):
         cfg4c = None
         if not args.no_config4 and not args.no_capi:
             if multi:
-                dist.barrier()        # every rank has released its config4 buffers
+                torch.cuda.synchronize()
+                dist.barrier(group=cpu_group)        # every rank has released its config4 buffers and its GPU is idle
             if rank == 0:
-                cfg4c = capi_leg_guarded(world, args.steps4, in_process=(world == 1))
+                cfg4c = capi_leg_guarded(world, args.steps4, in_process=(world == 1 and os.environ.get("ASX_BENCH_CAPI_CHILD") != "1"))
+            if multi:
+                dist.barrier(group=cpu_group)        # the others wait on the CPU, not in a kernel on the devices the leg uses
 
         single = None
         if world == 1 and not args.no_single:

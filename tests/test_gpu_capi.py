@@ -61,3 +61,26 @@ def test_bench_prints_exactly_one_json_line_on_stdout():
     assert "cpu_baseline" not in d          # --no-cpu
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+
+
+def test_bench_rank_path_with_the_capi_leg_as_a_child_process():
+    """the N > 1 form of bench.py on the one GPU there is: a rank under torch.distributed.run (ASX_BENCH_FORCE_DIST=1: process
+    group, RCCL gather, the gloo group the idle ranks wait in) whose config4_capi leg runs as a CHILD process with a time limit
+    (ASX_BENCH_CAPI_CHILD=1), as it does with more than one GPU; still ONE JSON line on stdout"""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    env = dict(os.environ, ASX_BENCH_FORCE_DIST="1", ASX_BENCH_CAPI_CHILD="1", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+           "--precondition", "1", "--no-cpu", "--steps4", "1"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines[:-1]
+    d = json.loads(lines[0])
+    assert d["results_ok"] and d["world_size_seen"] == 1 and d["config4"]["results_ok"]
+    assert d["config4_capi"].get("results_ok") is True and d["config4_capi"]["n_gpus"] == 1, d["config4_capi"]
