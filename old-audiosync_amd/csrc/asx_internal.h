@@ -136,9 +136,15 @@ struct AsxPeakWs {
                          // spectral form is not below the tolerance, or the segment is shorter than the wrap-around part
 #define ASX_PM_NMODES 3
 #define ASX_PRE_DOUBLES 8 // n, Sx, Sxx, Sy, Syy, r (plain sum scale), mode, bound
+#ifndef ASX_PREP_BLOCKS
+#define ASX_PREP_BLOCKS 4 // blocks of k_pearson_prep that share a pair's window sums on the long tracks (a function of the plan alone)
+#endif
+#define ASX_PREP_BLOCKS_MAX 16 // what the workspaces are sized for
 struct AsxSpecWs {
     AsxSeg *seg2;          // [pairs] what k_pearson_partial walks: nothing, the wrap-around part, or the segment itself
     double *pre;           // [pairs][ASX_PRE_DOUBLES]
+    double *part;          // [pairs][ASX_PREP_BLOCKS_MAX][4]; [pair][block][4] used: the blocks' shares of Sx, Sxx, Sy, Syy, merged in block order by the last to arrive
+    unsigned *done;        // [pairs] blocks of the pair that have left their share (back to zero when the last one has merged)
     unsigned long long *mode_count; // [ASX_PM_NMODES] cumulative
     double tol;            // a pair leaves the spectral form when its error bound exceeds this (1e-5: north_star's tolerance)
 };

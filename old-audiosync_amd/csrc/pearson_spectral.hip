@@ -28,6 +28,11 @@
 #include "xcorr_dev.h"
 
 
+static_assert(ASX_PREP_BLOCKS <= ASX_PREP_BLOCKS_MAX, "AsxSpecWs::part is sized for ASX_PREP_BLOCKS_MAX blocks per pair");
+#ifndef ASX_PREP_THREADS
+#define ASX_PREP_THREADS 1024 // per block of k_pearson_prep on the long tracks (ASX_PREP_BLOCKS blocks per pair)
+#endif
+
 namespace {
 
 struct Acc2 {
@@ -45,19 +50,20 @@ __device__ __forceinline__ void acc4(Acc2 &a, float4 v) { acc1(a, v.x); acc1(a, 
 // sum and sum of squares of track[lo .. hi) (float64 from the float32 samples), this thread's share: 16-byte loads over the
 // aligned middle (the track starts on a 16-byte boundary: 2N and N are multiples of four), the ragged ends by single lanes.
 // Four loads in flight per thread, each into its own accumulator (a fixed order all the same: the four are added at the end).
-template <int NTP> __device__ __forceinline__ void direct_range(const float *__restrict__ x, uint32_t lo, uint32_t hi, Acc2 &a)
+// NTP = the threads that share the range (all blocks of the pair), tid = this thread's index among them.
+template <uint32_t NTP> __device__ __forceinline__ void direct_range(const float *__restrict__ x, uint32_t lo, uint32_t hi, Acc2 &a, uint32_t tid)
 {
     if (lo >= hi) return;
     const uint32_t lo4 = (lo + 3u) & ~3u, hi4 = hi & ~3u;
     if (lo4 >= hi4) { // no aligned quad inside
-        for (uint32_t i = lo + threadIdx.x; i < hi; i += NTP) acc1(a, x[i]);
+        for (uint32_t i = lo + tid; i < hi; i += NTP) acc1(a, x[i]);
         return;
     }
-    if (threadIdx.x < lo4 - lo) acc1(a, x[lo + threadIdx.x]);
-    if (threadIdx.x < hi - hi4) acc1(a, x[hi4 + threadIdx.x]);
+    if (tid < lo4 - lo) acc1(a, x[lo + tid]);
+    if (tid < hi - hi4) acc1(a, x[hi4 + tid]);
     const float4 *q = reinterpret_cast<const float4 *>(x);
     const uint32_t end = hi4 >> 2;
-    uint32_t i = (lo4 >> 2) + threadIdx.x;
+    uint32_t i = (lo4 >> 2) + tid;
     Acc2 b{ 0.0, 0.0 }, c{ 0.0, 0.0 }, d{ 0.0, 0.0 };
     for (; i + 3u * NTP < end; i += 4u * NTP) {
         const float4 v0 = q[i], v1 = q[i + NTP], v2 = q[i + 2u * NTP], v3 = q[i + 3u * NTP];
@@ -72,19 +78,19 @@ template <int NTP> __device__ __forceinline__ void direct_range(const float *__r
 //   band: [ntiles][nbands] {sum, sum of squares} as k_fwd_cols_r left them (every block its own run); a band = gs consecutive samples.
 //   The (tile, band) cells of the window are dealt to the threads in order -- consecutive lanes walk the bands of a tile --
 //   and added in float64: a fixed order.
-template <int NTP> __device__ __forceinline__ Acc2 window_share(const float *__restrict__ x, const float2 *__restrict__ band, uint32_t gs, int ntiles,
-                                             int nbands, uint32_t lo, uint32_t hi)
+template <uint32_t NTP> __device__ __forceinline__ Acc2 window_share(const float *__restrict__ x, const float2 *__restrict__ band, uint32_t gs, int ntiles,
+                                             int nbands, uint32_t lo, uint32_t hi, uint32_t tid)
 {
     Acc2 a{ 0.0, 0.0 };
     const uint32_t ba = (lo + gs - 1) / gs, bb = hi / gs;
     if (ba < bb) {
-        direct_range<NTP>(x, lo, ba * gs, a);
-        direct_range<NTP>(x, bb * gs, hi, a);
+        direct_range<NTP>(x, lo, ba * gs, a, tid);
+        direct_range<NTP>(x, bb * gs, hi, a, tid);
         const uint32_t w = bb - ba, cells = w * (uint32_t)ntiles;
         const uint32_t dq = NTP / w, dr = NTP - dq * w; // one step of the cell index, as (tiles, bands)
-        uint32_t t = threadIdx.x / w, b = threadIdx.x - t * w;
+        uint32_t t = tid / w, b = tid - t * w;
         Acc2 e{ 0.0, 0.0 };
-        uint32_t i = threadIdx.x;
+        uint32_t i = tid;
         for (; i + NTP < cells; i += 2u * NTP) { // two cells in flight
             uint32_t t2 = t + dq, b2 = b + dr;
             if (b2 >= w) { b2 -= w; t2++; }
@@ -100,7 +106,7 @@ template <int NTP> __device__ __forceinline__ Acc2 window_share(const float *__r
         }
         a.s1 += e.s1; a.s2 += e.s2;
     } else {
-        direct_range<NTP>(x, lo, hi, a);
+        direct_range<NTP>(x, lo, hi, a, tid);
     }
     return a;
 }
@@ -125,9 +131,15 @@ template <int NTP> __device__ __forceinline__ void block_sum4(double (&v)[4], do
 
 } // namespace
 
-// grid (npairs), NTP threads (1024 for the long tracks -- up to 77 000 samples of band edges and 18 000 cells per pair -- 256 below:
+// grid (NB, npairs), NTP threads (1024 for the long tracks -- up to 77 000 samples of band edges and 18 000 cells per pair -- 256 below:
 // 1024 pairs of N = 144 000 took 61 us with 1024-thread blocks, the sixteen-wave fold of a few thousand numbers).  Picks the winner among the re-evaluated near-ties (if any), decides each pair's mode, leaves its window sums and r[peak] in pre[], its work list in seg2[].
-template <int NTP> __global__ __launch_bounds__(NTP) void k_pearson_prep(const AsxDev *__restrict__ Pp, const float *__restrict__ src,
+// NB > 1 (the long tracks): NB blocks share a pair's cells and edges -- NB * NTP threads dealt the same way -- each leaves its share of the
+// four sums, and the LAST to arrive (one returning atomic per block) adds the shares in block order and does the rest: the same bits
+// whichever block that is, and NB is a constant of the plan (the same pair takes the same tree alone, in a batch, on another shard).
+// Measured (profiles/r5_experiments/18_*): a single pair of N = 1 440 000 (BASELINE configs[1]) 91.5 -> 84-85 us per call with four blocks
+// (the kernel itself 25 -> 9 us; 0.7 MB sat behind ONE block's loads), a launch of 124 pairs the same (Pearson family 0.097 -> 0.099 ms);
+// eight or sixteen blocks per pair: the single pair no faster, the batch 0.114-0.156 ms (a fence and a returning atomic per block).
+template <int NTP, int NB> __global__ __launch_bounds__(NTP) void k_pearson_prep(const AsxDev *__restrict__ Pp, const float *__restrict__ src,
                                                                     const float *__restrict__ smp, AsxPeakWs W, AsxSpecWs S,
                                                                     AsxSeg *__restrict__ seg)
 {
@@ -137,7 +149,8 @@ template <int NTP> __global__ __launch_bounds__(NTP) void k_pearson_prep(const A
     __shared__ double rkey[NTP / 64], rval[NTP / 64];
     __shared__ uint32_t ridx[NTP / 64];
     __shared__ AsxSeg s_seg;
-    const size_t pair = blockIdx.x;
+    const size_t pair = blockIdx.y;
+    const uint32_t blk = blockIdx.x, gtid = blk * (uint32_t)NTP + threadIdx.x;
     const uint32_t N = Pp->N;
     const int M2 = Pp->M2, nbands = Pp->nbands;
     const uint32_t gs = (uint32_t)Pp->band_rows * (uint32_t)M2;
@@ -172,7 +185,7 @@ template <int NTP> __global__ __launch_bounds__(NTP) void k_pearson_prep(const A
             for (int w = 1; w < NTP / 64; w++)
                 if (rkey[w] > bk || (rkey[w] == bk && ridx[w] < bi)) { bk = rkey[w]; bi = ridx[w]; bv = rval[w]; }
             AsxSeg sg = seg[pair];
-            if (bi != 0xFFFFFFFFu) { sg = make_seg(bi, N); seg[pair] = sg; }
+            if (bi != 0xFFFFFFFFu) { sg = make_seg(bi, N); if (blk == 0) seg[pair] = sg; } // every block of the pair finds the same winner
             s_seg = sg;
             s_exact = bv;
             s_have_exact = bi != 0xFFFFFFFFu;
@@ -188,14 +201,38 @@ template <int NTP> __global__ __launch_bounds__(NTP) void k_pearson_prep(const A
     const bool direct = best == 0 || s.len == 0 || (s.flags & ASX_SEG_INEXACT) != 0;
     double n = (double)s.len, Sx = 0, Sxx = 0, Sy = 0, Syy = 0, r = 0, bound = INFINITY;
     int mode = ASX_PM_DIRECT;
+    if (direct && blk != 0) return; // (the same in every block of the pair)
     if (!direct) { // block-uniform
         const float *x = src + pair * (size_t)(2u * N), *y = smp + pair * (size_t)N;
         const int ntiles = Pp->ntiles;
         const float2 *bx = W.band + (size_t)pair * 2 * ntiles * nbands, *by = bx + (size_t)ntiles * nbands;
-        const Acc2 ax = window_share<NTP>(x, bx, gs, ntiles, nbands, s.src_off, s.src_off + s.len);
-        const Acc2 ay = window_share<NTP>(y, by, gs, ntiles, nbands, s.smp_off, s.smp_off + s.len);
+        const Acc2 ax = window_share<(uint32_t)NTP * NB>(x, bx, gs, ntiles, nbands, s.src_off, s.src_off + s.len, gtid);
+        const Acc2 ay = window_share<(uint32_t)NTP * NB>(y, by, gs, ntiles, nbands, s.smp_off, s.smp_off + s.len, gtid);
         double v[4] = { ax.s1, ax.s2, ay.s1, ay.s2 };
         block_sum4<NTP>(v, red);
+        if constexpr (NB > 1) {
+            __shared__ int s_last;
+            __shared__ double s_tot[4];
+            if (threadIdx.x == 0) {
+                double *mine = S.part + (pair * NB + blk) * 4;
+                for (int k = 0; k < 4; k++) __hip_atomic_store(mine + k, v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __threadfence();
+                const unsigned ticket = atomicAdd(S.done + pair, 1u);
+                s_last = ticket == (unsigned)(NB - 1);
+                if (s_last) {
+                    __threadfence();
+                    for (int k = 0; k < 4; k++) {
+                        double t = 0.0;
+                        for (int b = 0; b < NB; b++) t += __hip_atomic_load(S.part + (pair * NB + b) * 4 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        s_tot[k] = t;
+                    }
+                    __hip_atomic_store(S.done + pair, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // ready for the next call
+                }
+            }
+            __syncthreads();
+            if (!s_last) return;
+            for (int k = 0; k < 4; k++) v[k] = s_tot[k];
+        }
         Sx = v[0]; Sxx = v[1]; Sy = v[2]; Syy = v[3];
         // r[peak] in the plain-sum scale and the bound on its error
         double rb;
@@ -271,9 +308,9 @@ void asx_launch_pearson_spectral_f32(const AsxDev &P, const float *src, const fl
                                      hipStream_t s)
 {
     if ((size_t)P.band_rows * (size_t)P.M2 >= 16384)
-        hipLaunchKernelGGL(k_pearson_prep<1024>, dim3(npairs), dim3(1024), 0, s, P.self_dev, src, smp, W, S, seg);
+        hipLaunchKernelGGL((k_pearson_prep<ASX_PREP_THREADS, ASX_PREP_BLOCKS>), dim3(ASX_PREP_BLOCKS, npairs), dim3(ASX_PREP_THREADS), 0, s, P.self_dev, src, smp, W, S, seg);
     else
-        hipLaunchKernelGGL(k_pearson_prep<256>, dim3(npairs), dim3(256), 0, s, P.self_dev, src, smp, W, S, seg);
+        hipLaunchKernelGGL((k_pearson_prep<256, 1>), dim3(1, npairs), dim3(256), 0, s, P.self_dev, src, smp, W, S, seg);
     asx_launch_pearson_partial_f32(src, smp, 2 * (size_t)P.N, P.N, P.N, S.seg2, psums, npairs, s);
     hipLaunchKernelGGL(k_pearson_final_spec, dim3(npairs), dim3(64), 0, s, seg, psums, asx_pearson_blocks(P.N), S.pre, lag, coef, ret);
 }
