@@ -146,6 +146,15 @@ __device__ __forceinline__ void st_f2(float2 *p, float2 v, bool nt)
 #define ASX_ROWS2_SCHED 12, 10, 10
 #endif
 
+// k_rows_r, which table look-ups are issued ahead of the loads they would otherwise queue behind (vmcnt completes in order):
+// bit 0 = the block's tw_step / leg entries BEFORE the row loads (the barrier in front of the load phase's arithmetic then waits for an
+// L2 round trip that overlaps the HBM loads instead of following them); bit 1 = the twiddles of the two-half form's store phase at
+// the top of the kernel instead of behind its last barrier
+// Measured (profiles/r5_experiments/19_*, four alternating rounds): bit 1 rows 0.931 -> 0.918 ms (the store phase started with an L2 round
+// trip on the two waves that run it); bit 0 nothing (0.930); both 0.921.  Default: bit 1.
+#ifndef ASX_ROWS_EARLY
+#define ASX_ROWS_EARLY 2
+#endif
 #ifndef ASX_ROWSR_WAVES
 #define ASX_ROWSR_WAVES 4 // waves per SIMD the register allocation must allow: 8 blocks of 2 waves per CU
 #endif
@@ -210,6 +219,22 @@ __global__ __launch_bounds__(TWO ? 2 * NT : NT, ASX_ROWSR_WAVES) void k_rows_r(c
             W.cand_n[pair] = 0;
         }
     }
+    const bool is_step = tid < WSTEPS, is_leg = tid >= NTB - R0;
+    static_assert(WSTEPS <= NTB - R0, "the threads that fill tw_step and leg are different threads");
+    float2 pre_lo = make_float2(1.f, 0.f), pre_hi = pre_lo;
+    if ((ASX_ROWS_EARLY & 1) && (is_step || is_leg)) {
+        const uint32_t p = is_step ? k1 * (uint32_t)(2 * NTB * tid) : k1 * (uint32_t)(Q0 * (tid - (NTB - R0)));
+        pre_lo = P.tw_lo[p & (ASX_TW_LO - 1u)];
+        pre_hi = P.tw_hi[p >> ASX_TW_LOG];
+    }
+    // the look-ups of the two-half form's store phase (threads [0, Q0): butterfly j = tid)
+    float2 tail_w2 = make_float2(1.f, 0.f), tail_lo = tail_w2, tail_hi = tail_w2;
+    if (TWO && (ASX_ROWS_EARLY & 2) && tid < Q0) {
+        const uint32_t p = k1 * (uint32_t)tid;
+        tail_w2 = P.tw2[tid];
+        tail_lo = P.tw_lo[p & (ASX_TW_LO - 1u)];
+        tail_hi = P.tw_hi[p >> ASX_TW_LOG];
+    }
     // every row load of the thread first; the twiddle lookups below overlap them
     float4 lx[WSTEPS], ly[WSTEPS], lx2[TWO ? WSTEPS : 1], ly2[TWO ? WSTEPS : 1];
     {
@@ -226,12 +251,12 @@ __global__ __launch_bounds__(TWO ? 2 * NT : NT, ASX_ROWSR_WAVES) void k_rows_r(c
             }
         });
     }
-    if (tid < WSTEPS) {
+    if (is_step) {
         // ... times 1/2: k_fwd_cols_r stores 2 C (its untangling without the halving)
-        const float2 t = tw_F(P, k1 * (uint32_t)(2 * NTB * tid));
+        const float2 t = (ASX_ROWS_EARLY & 1) ? cmul(pre_lo, pre_hi) : tw_F(P, k1 * (uint32_t)(2 * NTB * tid));
         tw_step[tid] = make_float2(0.5f * t.x, 0.5f * t.y);
     }
-    if (tid >= NTB - R0) { const int t = tid - (NTB - R0); leg[t] = tw_F(P, k1 * (uint32_t)(Q0 * t)); }
+    if (is_leg) { const int t = tid - (NTB - R0); leg[t] = (ASX_ROWS_EARLY & 1) ? cmul(pre_lo, pre_hi) : tw_F(P, k1 * (uint32_t)(Q0 * t)); }
     const float2 twa = tw_F(P, k1 * (uint32_t)(2 * tid < NS ? 2 * tid : 0)); // w_F^(k1 * 2 tid)
     const float2 wk1 = tw_F(P, k1);
     const float2 wh = TWO ? tw_F(P, k1 * (uint32_t)NS) : make_float2(1.f, 0.f); // w_F^(k1 n): from c[j] to c[j + n]
@@ -359,6 +384,7 @@ __global__ __launch_bounds__(TWO ? 2 * NT : NT, ASX_ROWSR_WAVES) void k_rows_r(c
         // (w_M2^(j + Q0 t) = w_M2^j times the compile-time root w_{2 R0}^t), then the conjugate four-step twiddles.
         // Only Q0 threads work here; the others are done.
         const float4 *base = reinterpret_cast<const float4 *>(asx_lds_r);
+        static_assert(Q0 <= NT, "one butterfly per thread of the first half");
         for (int j = tid; j < Q0; j += NTB) {
             Cx2 v[R0];
             static_for<0, R0>([&](auto T) __attribute__((always_inline)) {
@@ -366,11 +392,12 @@ __global__ __launch_bounds__(TWO ? 2 * NT : NT, ASX_ROWSR_WAVES) void k_rows_r(c
                 v[T] = Cx2{ v2f{ a.re, b.re }, v2f{ a.im, b.im } };
             });
             float2 tww[R0];
-            stage_twiddles_from<R0>(P.tw2[TWS * j], P.tw2[TWS * 4 * j], tww);
+            if constexpr (ASX_ROWS_EARLY & 2) stage_twiddles_from<R0>(s0w1, s0w4, tww); // j = tid = lt here: the seeds of forward stage 0
+            else stage_twiddles_from<R0>(P.tw2[TWS * j], P.tw2[TWS * 4 * j], tww);
             static_for<1, R0>([&](auto U) __attribute__((always_inline)) { v[U] = mulwc(v[U], tww[U]); });
             Bfly<R0, true>::run(v);
-            const float2 w2 = P.tw2[j];                       // w_M2^j
-            const float2 fa = tw_F(P, k1 * (uint32_t)j);      // w_F^(k1 j)
+            const float2 w2 = (ASX_ROWS_EARLY & 2) ? tail_w2 : P.tw2[j];                                  // w_M2^j
+            const float2 fa = (ASX_ROWS_EARLY & 2) ? cmul(tail_lo, tail_hi) : tw_F(P, k1 * (uint32_t)j);  // w_F^(k1 j)
             const float2 fbh = cmul(fa, wh);                  // w_F^(k1 (j + n))
             static_for<0, R0>([&](auto T) __attribute__((always_inline)) {
                 constexpr int t = decltype(T)::value;

@@ -19,8 +19,10 @@ L.cross_correlation.restype = ctypes.c_int
 L.cross_correlation.argtypes = [dp, dp, ctypes.c_size_t, ctypes.POINTER(ctypes.c_long), dp]
 PROD = [144000, 288000, 480000] if os.environ.get("FUZZ_BIG") == "1" else [144000, 288000]
 if os.environ.get("FUZZ_HUGE") == "1": PROD = [720000, 960000, 1440000]
-t0 = time.time(); trials = checked = 0; layouts = {}; modes = [0, 0, 0]; worst = 0.0
+t0 = time.time(); trials = checked = 0; layouts = {}; modes = [0, 0, 0]; worst = 0.0; said = t0
 while time.time() - t0 < budget:
+    if time.time() - said > 60.0:   # gpurun takes a command that writes nothing for seven minutes to be hung
+        said = time.time(); print("... %d problems, %d pairs checked after %.0f s" % (trials, checked, said - t0), flush=True)
     r = rng.uniform()
     if os.environ.get("FUZZ_BIG") == "1": r *= 0.5   # FUZZ_BIG=1: only the production and the large lengths
     if os.environ.get("FUZZ_HUGE") == "1": r = 0.0   # FUZZ_HUGE=1: only 15 / 20 / 30 s (720 000, 960 000, 1 440 000)
