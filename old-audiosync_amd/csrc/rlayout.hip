@@ -516,7 +516,9 @@ __global__ __launch_bounds__(NT, 4) void k_fwd_cols_r(const RArgs P, const float
     if ((threadIdx.x & 63) == 0) nrm_red[threadIdx.x >> 6] = ss;
     __syncthreads();
     (void)lds_fft_static_head<S1, false, true>(lds4, Lc, P.tw1, pre); // every stage but the innermost one
-    if (threadIdx.x == 0) {
+    // The LAST thread: it has no work item in the store phase below.  (Thread 0's wave waited for this store before its first butterfly
+    // of that phase, at the end of the block's life where nothing hides it: 0.997 -> 0.979 ms, profiles/r5_experiments/20_*.)
+    if (threadIdx.x == NT - 1) {
         float t = nrm_red[0];
         for (int w = 1; w < NT / 64; w++) t += nrm_red[w];
         nrm_part[(pair * 2 + which) * (size_t)P.ntiles + tile] = t;
@@ -533,6 +535,7 @@ __global__ __launch_bounds__(NT, 4) void k_fwd_cols_r(const RArgs P, const float
     constexpr int RL = S1::stage(2).R, R0c = S1::stage(0).R, R1c = S1::stage(1).R, MB = M1 / RL;
     static_assert(S1::stage(2).q == 1 && MB == R0c * R1c && MB % 2 == 0, "innermost stage of consecutive slots");
     constexpr int NBPAIRS = (MB / 2) * H;
+    static_assert(NBPAIRS <= NT - 1, "one work item per thread at most, none for the last thread");
     for (int e = threadIdx.x; e < NBPAIRS; e += NT) {
         const int g = e & (H - 1), v = e >> logH;  // v = u_b in [0, MB/2)
         const int ub = v, ubp = v == 0 ? MB / 2 : MB - v;
@@ -627,10 +630,11 @@ __global__ __launch_bounds__(NT, 4) void k_inv_cols_r(const RArgs P, const float
     const LdsLayout Lc = col_layout(T, logT, NT);
     // the pair's running maximum so far and the width of the near-maximum window: fetched now, used behind the barriers
     const float b2_early = W.bound2[pair];
-    if (threadIdx.x == 0) {
-        s_run0 = W.pairmax[pair];
-        s_b2 = b2_early;
-    }
+    // (thread 0 asks for the running maximum here and leaves it in LDS BEHIND the tile loads: stored at once, its wave sat out a memory
+    // round trip before it issued its share of the tile's loads, and the block's first barrier waited for that wave: 0.3195 -> 0.3145 ms
+    // at 600 rows, -1 % at 400; every thread asking instead: +3 % at 600 rows, profiles/r5_experiments/20_*)
+    asx_peak_t run0_early = 0;
+    if (threadIdx.x == 0) run0_early = W.pairmax[pair];
     // ---- first stage to run (the innermost, radix RL = R_last, RL consecutive slots per butterfly), fed from HBM --------
     // Butterfly b of a column pair holds the frequencies u_b + MB t (t < RL, MB = M1 / RL, u_b = digit swap of b); their
     // tangling partners M1 - u_b - MB t are element RL-1-t of butterfly b' (u_b' = MB - u_b).  A work item takes BOTH
@@ -701,6 +705,10 @@ __global__ __launch_bounds__(NT, 4) void k_inv_cols_r(const RArgs P, const float
             lds_put(pa + (decltype(TT)::value << logH), za[TT]);
             lds_put(pb + (decltype(TT)::value << logH), zb[TT]);
         });
+    }
+    if (threadIdx.x == 0) {
+        s_run0 = run0_early;
+        s_b2 = b2_early;
     }
     RSTAMP(2, sblock, 1);
     // A digitally silent track (zero norm: r is exactly zero everywhere): the running maximum stays zero, which k_finalize
