@@ -437,6 +437,22 @@ static inline unsigned rcol_grid_x(int ntiles, int logT)
     return ((unsigned)ntiles + grp - 1) / grp * grp;
 }
 
+// The work items v = 0 of the column kernels' register stage (the butterflies that pair with themselves: H of (MB / 2) H items, a branch
+// of their own) sit in the LAST H threads of the block when that leaves them a wave of their own (600- and 400-row tiles: 392 / 312
+// regular items, 512 threads): with them in threads [0, H), wave 0 ran both branches one after the other -- in k_fwd_cols_r at the very
+// end of the block's life, in k_inv_cols_r with a row load of its own behind the others.  Forward / inverse columns 0.989 -> 0.978 /
+// 0.314 -> 0.310 ms at 600 rows, 2.766 -> 2.746 / 1.049 -> 1.019 at 400; 300-row tiles (256 threads, no idle wave): +1.5 % / 0, left alone
+// (profiles/r5_experiments/21_*; -DASX_SPECIAL_LAST=0: the old order everywhere).
+#ifndef ASX_SPECIAL_LAST
+#define ASX_SPECIAL_LAST 1
+#endif
+// item of thread t: regular items e = H .. NITEMS-1 in threads [0, NITEMS - H), the H special ones in threads [NT - H, NT); -1 = none
+template <int NITEMS, int H, int NT> __device__ __forceinline__ int rcol_item_of_thread(int t)
+{
+    constexpr bool own_wave = NITEMS - H <= NT - 64;
+    if (!ASX_SPECIAL_LAST || !own_wave) return t < NITEMS ? t : -1;
+    return t < NITEMS - H ? t + H : t >= NT - H ? t - (NT - H) : -1;
+}
 #ifndef ASX_RCOL_LOADS
 #define ASX_RCOL_LOADS 5 // row-pair pieces (two 16-byte loads each) a thread keeps in flight
 #endif
@@ -516,9 +532,9 @@ __global__ __launch_bounds__(NT, 4) void k_fwd_cols_r(const RArgs P, const float
     if ((threadIdx.x & 63) == 0) nrm_red[threadIdx.x >> 6] = ss;
     __syncthreads();
     (void)lds_fft_static_head<S1, false, true>(lds4, Lc, P.tw1, pre); // every stage but the innermost one
-    // The LAST thread: it has no work item in the store phase below.  (Thread 0's wave waited for this store before its first butterfly
+    // A thread that has no work item in the store phase below (rcol_item_of_thread).  (Thread 0's wave waited for this store before its first butterfly
     // of that phase, at the end of the block's life where nothing hides it: 0.997 -> 0.979 ms, profiles/r5_experiments/20_*.)
-    if (threadIdx.x == NT - 1) {
+    if (threadIdx.x == NT - H - 1) {
         float t = nrm_red[0];
         for (int w = 1; w < NT / 64; w++) t += nrm_red[w];
         nrm_part[(pair * 2 + which) * (size_t)P.ntiles + tile] = t;
@@ -535,8 +551,8 @@ __global__ __launch_bounds__(NT, 4) void k_fwd_cols_r(const RArgs P, const float
     constexpr int RL = S1::stage(2).R, R0c = S1::stage(0).R, R1c = S1::stage(1).R, MB = M1 / RL;
     static_assert(S1::stage(2).q == 1 && MB == R0c * R1c && MB % 2 == 0, "innermost stage of consecutive slots");
     constexpr int NBPAIRS = (MB / 2) * H;
-    static_assert(NBPAIRS <= NT - 1, "one work item per thread at most, none for the last thread");
-    for (int e = threadIdx.x; e < NBPAIRS; e += NT) {
+    static_assert(NBPAIRS <= NT - 1, "one work item per thread at most, none for thread NT - H - 1 (the block's norm)");
+    if (const int e = rcol_item_of_thread<NBPAIRS, H, NT>(threadIdx.x); e >= 0) {
         const int g = e & (H - 1), v = e >> logH;  // v = u_b in [0, MB/2)
         const int ub = v, ubp = v == 0 ? MB / 2 : MB - v;
         const int d1 = ub / R0c, d0 = ub - d1 * R0c, e1 = ubp / R0c, e0 = ubp - e1 * R0c;
@@ -651,7 +667,8 @@ __global__ __launch_bounds__(NT, 4) void k_inv_cols_r(const RArgs P, const float
     const size_t sblock = pair * (size_t)(P.M2 / T) + tile; (void)sblock;
     RSTAMP(2, sblock, 0);
     const TwPre pre_mid = tw_prefetch_exec<S1, 1, true, true, true>(Lc, P.tw1);
-    for (int e = threadIdx.x; e < NITEMS; e += NT) {
+    static_assert(NITEMS <= NT, "one work item per thread at most");
+    if (const int e = rcol_item_of_thread<NITEMS, H, NT>(threadIdx.x); e >= 0) {
         const int g = e & (H - 1), v = e >> logH;  // v = u_b in [0, MB/2)
         const int ub = v, ubp = v == 0 ? MB / 2 : MB - v; // first rows of the two butterflies' row sets
         const float2 *ca = in + (size_t)ub * M2 + c0 + 2 * g, *cb = in + (size_t)ubp * M2 + c0 + 2 * g;
