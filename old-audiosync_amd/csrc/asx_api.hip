@@ -257,10 +257,8 @@ static int plan_init(asx_plan *p, size_t N, size_t max_batch, const char *split)
                 HIP_TRY(hipMemset(p->mode_count, 0, ASX_PM_NMODES * sizeof(unsigned long long)));
             }
             if (dev_alloc(p, &ln.pk.band, g * 2 * nbands * (size_t)h.ntiles) || dev_alloc(p, &ln.pk.tile_peak, g * (size_t)(h.M2 / h.T)) ||
-                dev_alloc(p, &ln.spec.seg2, g) || dev_alloc(p, &ln.spec.pre, g * ASX_PRE_DOUBLES) ||
-                dev_alloc(p, &ln.spec.part, g * ASX_PREP_BLOCKS_MAX * 4) || dev_alloc(p, &ln.spec.done, g))
+                dev_alloc(p, &ln.spec.part, g * ASX_PREP_BLOCKS_MAX * 4) || dev_alloc(p, &ln.spec.hdr, g * ASX_SPEC_HDR))
                 return -1;
-            HIP_TRY(hipMemset(ln.spec.done, 0, g * sizeof(unsigned)));
             ln.spec.mode_count = p->mode_count;
             ln.spec.tol = 1e-5;
         }

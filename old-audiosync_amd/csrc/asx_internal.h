@@ -135,18 +135,22 @@ struct AsxPeakWs {
 #define ASX_PM_DIRECT 2  // the reference's own reduction over the segment (src/cross_correlation.c:74-116): the error bound of the
                          // spectral form is not below the tolerance, or the segment is shorter than the wrap-around part
 #define ASX_PM_NMODES 3
-#define ASX_PRE_DOUBLES 8 // n, Sx, Sxx, Sy, Syy, r (plain sum scale), mode, bound
 #ifndef ASX_PREP_BLOCKS
 #define ASX_PREP_BLOCKS 4 // blocks of k_pearson_prep that share a pair's window sums on the long tracks (a function of the plan alone)
 #endif
 #define ASX_PREP_BLOCKS_MAX 16 // what the workspaces are sized for
+#define ASX_SPEC_HDR 4    // per pair: r[peak] (plain sum scale), the bound on its error, 1.0 = "the direct reduction, whatever it yields", spare
+// What k_pearson_prep leaves and what reads it: the blocks' SHARES of the four window sums and a header -- no merged record.  The mode of a
+// pair (asx_spec_pick, xcorr_dev.h: a few dozen float64 operations on 4 * nb + 3 numbers) is worked out again by every block of
+// k_pearson_partial and by k_pearson_final_spec: a merge by the last block to arrive cost a device-scope fence per block (28.8 against
+// 19.5 us per launch of 124 pairs, profiles/r5_experiments/22_*).
 struct AsxSpecWs {
-    AsxSeg *seg2;          // [pairs] what k_pearson_partial walks: nothing, the wrap-around part, or the segment itself
-    double *pre;           // [pairs][ASX_PRE_DOUBLES]
-    double *part;          // [pairs][ASX_PREP_BLOCKS_MAX][4]; [pair][block][4] used: the blocks' shares of Sx, Sxx, Sy, Syy, merged in block order by the last to arrive
-    unsigned *done;        // [pairs] blocks of the pair that have left their share (back to zero when the last one has merged)
+    double *part;          // [pairs][nb][4] the blocks' shares of Sx, Sxx, Sy, Syy, added in block order by whoever reads them
+    double *hdr;           // [pairs][ASX_SPEC_HDR]
     unsigned long long *mode_count; // [ASX_PM_NMODES] cumulative
     double tol;            // a pair leaves the spectral form when its error bound exceeds this (1e-5: north_star's tolerance)
+    int nb;                // blocks of k_pearson_prep per pair (set by the launcher: 1 or ASX_PREP_BLOCKS)
+    uint32_t N;            // sample_len (set by the launcher)
 };
 
 void asx_launch_fwd_cols(const AsxDev &P, const float *src, const float *smp, float2 *zxa,
@@ -176,8 +180,8 @@ void asx_launch_pearson_f64(const double *src, const double *smp, size_t src_pit
                             uint32_t basis_len, const AsxSeg *seg, double *psums, int64_t *lag,
                             double *coef, int32_t *ret, int npairs, hipStream_t s);
 // the partial-sum kernel alone (the spectral form runs it on its own segment list, pearson_spectral.hip)
-void asx_launch_pearson_partial_f32(const float *src, const float *smp, size_t src_pitch, size_t smp_pitch,
-                                    uint32_t basis_len, const AsxSeg *seg, double *psums, int npairs, hipStream_t s);
+void asx_launch_pearson_partial_spec_f32(const float *src, const float *smp, size_t src_pitch, size_t smp_pitch, uint32_t basis_len,
+                                         const AsxSeg *seg, const AsxSpecWs &S, double *psums, int npairs, hipStream_t s);
 // pearson_spectral.hip: float32 inputs, real-column plans (W.band and W.tile_peak filled by this group's transform kernels)
 void asx_launch_pearson_spectral_f32(const AsxDev &P, const float *src, const float *smp, const AsxPeakWs &W, const AsxSpecWs &S,
                                      AsxSeg *seg, double *psums, int64_t *lag, double *coef, int32_t *ret, int npairs,

@@ -132,13 +132,11 @@ template <int NTP> __device__ __forceinline__ void block_sum4(double (&v)[4], do
 } // namespace
 
 // grid (NB, npairs), NTP threads (1024 for the long tracks -- up to 77 000 samples of band edges and 18 000 cells per pair -- 256 below:
-// 1024 pairs of N = 144 000 took 61 us with 1024-thread blocks, the sixteen-wave fold of a few thousand numbers).  Picks the winner among the re-evaluated near-ties (if any), decides each pair's mode, leaves its window sums and r[peak] in pre[], its work list in seg2[].
-// NB > 1 (the long tracks): NB blocks share a pair's cells and edges -- NB * NTP threads dealt the same way -- each leaves its share of the
-// four sums, and the LAST to arrive (one returning atomic per block) adds the shares in block order and does the rest: the same bits
-// whichever block that is, and NB is a constant of the plan (the same pair takes the same tree alone, in a batch, on another shard).
-// Measured (profiles/r5_experiments/18_*): a single pair of N = 1 440 000 (BASELINE configs[1]) 91.5 -> 84-85 us per call with four blocks
-// (the kernel itself 25 -> 9 us; 0.7 MB sat behind ONE block's loads), a launch of 124 pairs the same (Pearson family 0.097 -> 0.099 ms);
-// eight or sixteen blocks per pair: the single pair no faster, the batch 0.114-0.156 ms (a fence and a returning atomic per block).
+// 1024 pairs of N = 144 000 took 61 us with 1024-thread blocks, the sixteen-wave fold of a few thousand numbers).  Picks the winner among the re-evaluated near-ties (if any) and leaves the pair's window-sum shares and r[peak] (AsxSpecWs).
+// NB > 1 (the long tracks): NB blocks share a pair's cells and edges -- NB * NTP threads dealt the same way -- and each leaves its SHARE of the
+// four sums; the kernels behind this one add the shares in block order (asx_spec_pick): the same bits whoever adds them, and NB is a
+// constant of the plan (the same pair takes the same tree alone, in a batch, on another shard).  No merged record, hence no fence and no
+// ticket: profiles/r5_experiments/18_* (one block per pair: 25 us for a single pair behind ONE block's loads) and 22_*.
 template <int NTP, int NB> __global__ __launch_bounds__(NTP) void k_pearson_prep(const AsxDev *__restrict__ Pp, const float *__restrict__ src,
                                                                     const float *__restrict__ smp, AsxPeakWs W, AsxSpecWs S,
                                                                     AsxSeg *__restrict__ seg)
@@ -154,7 +152,6 @@ template <int NTP, int NB> __global__ __launch_bounds__(NTP) void k_pearson_prep
     const uint32_t N = Pp->N;
     const int M2 = Pp->M2, nbands = Pp->nbands;
     const uint32_t gs = (uint32_t)Pp->band_rows * (uint32_t)M2;
-    double *pre = S.pre + pair * ASX_PRE_DOUBLES;
     const asx_peak_t best = W.pairmax[pair];
     // ---- k_refine_pick's part (xcorr_kernels.hip; this kernel stands in for it in the spectral form: one launch less): the
     // reference's max_abs_index rule (src/cross_correlation.c:52-67) on the exact values of the re-evaluated near-ties --
@@ -199,81 +196,43 @@ template <int NTP, int NB> __global__ __launch_bounds__(NTP) void k_pearson_prep
     // A pair the transforms had nothing to say about (silent or NaN track: no maximum), an empty segment, or a lag that is still
     // the float32 placeholder of an overflowed list (the second look redoes it): the direct reduction, whatever it yields.
     const bool direct = best == 0 || s.len == 0 || (s.flags & ASX_SEG_INEXACT) != 0;
-    double n = (double)s.len, Sx = 0, Sxx = 0, Sy = 0, Syy = 0, r = 0, bound = INFINITY;
-    int mode = ASX_PM_DIRECT;
-    if (direct && blk != 0) return; // (the same in every block of the pair)
-    if (!direct) { // block-uniform
-        const float *x = src + pair * (size_t)(2u * N), *y = smp + pair * (size_t)N;
-        const int ntiles = Pp->ntiles;
-        const float2 *bx = W.band + (size_t)pair * 2 * ntiles * nbands, *by = bx + (size_t)ntiles * nbands;
-        const Acc2 ax = window_share<(uint32_t)NTP * NB>(x, bx, gs, ntiles, nbands, s.src_off, s.src_off + s.len, gtid);
-        const Acc2 ay = window_share<(uint32_t)NTP * NB>(y, by, gs, ntiles, nbands, s.smp_off, s.smp_off + s.len, gtid);
-        double v[4] = { ax.s1, ax.s2, ay.s1, ay.s2 };
-        block_sum4<NTP>(v, red);
-        if constexpr (NB > 1) {
-            __shared__ int s_last;
-            __shared__ double s_tot[4];
-            if (threadIdx.x == 0) {
-                double *mine = S.part + (pair * NB + blk) * 4;
-                for (int k = 0; k < 4; k++) __hip_atomic_store(mine + k, v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __threadfence();
-                const unsigned ticket = atomicAdd(S.done + pair, 1u);
-                s_last = ticket == (unsigned)(NB - 1);
-                if (s_last) {
-                    __threadfence();
-                    for (int k = 0; k < 4; k++) {
-                        double t = 0.0;
-                        for (int b = 0; b < NB; b++) t += __hip_atomic_load(S.part + (pair * NB + b) * 4 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        s_tot[k] = t;
-                    }
-                    __hip_atomic_store(S.done + pair, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // ready for the next call
-                }
-            }
-            __syncthreads();
-            if (!s_last) return;
-            for (int k = 0; k < 4; k++) v[k] = s_tot[k];
-        }
-        Sx = v[0]; Sxx = v[1]; Sy = v[2]; Syy = v[3];
-        // r[peak] in the plain-sum scale and the bound on its error
-        double rb;
-        if (s_have_exact) { r = s_exact; rb = 0.0; }
-        else {
-            const int T = Pp->T;
-            r = (double)W.tile_peak[pair * (size_t)(M2 / T) + (s.peak % (uint32_t)M2) / (uint32_t)T] / (double)Pp->F;
-            rb = 0.5 * (double)W.bound2[pair] / (double)Pp->F; // bound2 = 2B in the device's scale (F times the plain sum)
-        }
-        const double A = Sxx - Sx * Sx / n, B = Syy - Sy * Sy / n;
-        if (A > 0.0 && B > 0.0) {
-            // float32 band sums: <= 16 eps relative on a sum of squares, <= 16 eps * sum|x| <= 16 eps sqrt(n Sxx) on a plain sum
-            const double es = 16.0 * 5.9604645e-8;
-            const double dSx = es * sqrt(n * Sxx), dSy = es * sqrt(n * Syy);
-            const double dC = rb + (fabs(Sy) * dSx + fabs(Sx) * dSy) / n;
-            const double dA = es * Sxx + 2.0 * fabs(Sx) / n * dSx, dB = es * Syy + 2.0 * fabs(Sy) / n * dSy;
-            bound = dC / sqrt(A * B) + 0.5 * (dA / A + dB / B); // |coefficient| <= 1
-            if (bound <= S.tol) {
-                if (s.peak < N) mode = ASX_PM_FAST;
-                else if (N - s.len < s.len) mode = ASX_PM_CORR; // |lag| products instead of L
+    if (blk == 0 && threadIdx.x == 0) {
+        // the header: r[peak] in the plain-sum scale and the bound on its error
+        double r = 0.0, rb = 0.0;
+        if (!direct) {
+            if (s_have_exact) r = s_exact;
+            else {
+                const int T = Pp->T;
+                r = (double)W.tile_peak[pair * (size_t)(M2 / T) + (s.peak % (uint32_t)M2) / (uint32_t)T] / (double)Pp->F;
+                rb = 0.5 * (double)W.bound2[pair] / (double)Pp->F; // bound2 = 2B in the device's scale (F times the plain sum)
             }
         }
+        double *hdr = S.hdr + pair * ASX_SPEC_HDR;
+        hdr[0] = r; hdr[1] = rb; hdr[2] = direct ? 1.0 : 0.0; hdr[3] = 0.0;
     }
+    if (direct) return; // block-uniform, and the same in every block of the pair: nobody reads its shares
+    const float *x = src + pair * (size_t)(2u * N), *y = smp + pair * (size_t)N;
+    const int ntiles = Pp->ntiles;
+    const float2 *bx = W.band + (size_t)pair * 2 * ntiles * nbands, *by = bx + (size_t)ntiles * nbands;
+    const Acc2 ax = window_share<(uint32_t)NTP * NB>(x, bx, gs, ntiles, nbands, s.src_off, s.src_off + s.len, gtid);
+    const Acc2 ay = window_share<(uint32_t)NTP * NB>(y, by, gs, ntiles, nbands, s.smp_off, s.smp_off + s.len, gtid);
+    double v[4] = { ax.s1, ax.s2, ay.s1, ay.s2 };
+    block_sum4<NTP>(v, red);
     if (threadIdx.x == 0) {
-        AsxSeg w = s;
-        if (mode == ASX_PM_FAST) w.len = 0;
-        else if (mode == ASX_PM_CORR) { w.src_off = s.peak; w.smp_off = 0; w.len = N - s.len; }
-        S.seg2[pair] = w;
-        pre[0] = n; pre[1] = Sx; pre[2] = Sxx; pre[3] = Sy; pre[4] = Syy; pre[5] = r; pre[6] = (double)mode; pre[7] = bound;
-        atomicAdd(S.mode_count + mode, 1ull);
+        double *mine = S.part + (pair * NB + blk) * 4;
+        mine[0] = v[0]; mine[1] = v[1]; mine[2] = v[2]; mine[3] = v[3];
     }
 }
 
 // grid (npairs), one wave per pair: k_pearson_final (xcorr_kernels.hip) with the two spectral modes in front of it.
 __global__ __launch_bounds__(64) void k_pearson_final_spec(const AsxSeg *__restrict__ seg, const double *__restrict__ psums, uint32_t nb,
-                                                            const double *__restrict__ pre_all, int64_t *__restrict__ lag,
+                                                            AsxSpecWs S, int64_t *__restrict__ lag,
                                                             double *__restrict__ coef, int32_t *__restrict__ ret)
 {
     const size_t pair = blockIdx.x;
-    const double *pre = pre_all + pair * ASX_PRE_DOUBLES;
-    const int mode = (int)pre[6];
+    const AsxSeg s = seg[pair];
+    const AsxSpecPick d = asx_spec_pick(s, S.part + pair * (size_t)(S.nb * 4), S.nb, S.hdr + pair * ASX_SPEC_HDR, S.tol, S.N);
+    const int mode = d.mode;
     PStat v;
     v.n = v.mx = v.my = v.mxx = v.myy = v.cxy = 0.0;
     if (mode != ASX_PM_FAST) { // wave-uniform
@@ -286,13 +245,12 @@ __global__ __launch_bounds__(64) void k_pearson_final_spec(const AsxSeg *__restr
         v = pstat_wave_merge(v);
     }
     if (threadIdx.x == 0) {
-        const AsxSeg s = seg[pair];
         double c;
         if (mode == ASX_PM_DIRECT) {
             c = v.cxy / sqrt(v.mxx * v.myy); // src/cross_correlation.c:115
         } else {
-            const double n = pre[0], Sx = pre[1], Sxx = pre[2], Sy = pre[3], Syy = pre[4];
-            double sxy = pre[5];
+            const double n = d.n, Sx = d.Sx, Sxx = d.Sxx, Sy = d.Sy, Syy = d.Syy;
+            double sxy = d.r;
             if (mode == ASX_PM_CORR) sxy -= v.cxy + v.n * v.mx * v.my; // minus the products that did not wrap around
             c = (sxy - Sx * Sy / n) / sqrt((Sxx - Sx * Sx / n) * (Syy - Sy * Sy / n));
             c = c > 1.0 ? 1.0 : c < -1.0 ? -1.0 : c; // the reference's value cannot leave [-1, 1]; NaN stays NaN
@@ -300,17 +258,23 @@ __global__ __launch_bounds__(64) void k_pearson_final_spec(const AsxSeg *__restr
         if (lag) lag[pair] = s.lag;
         coef[pair] = c;
         if (ret) ret[pair] = (s.flags & ASX_SEG_INEXACT) ? 1 : (c != c) ? -1 : 0; // as k_pearson_final (:276)
+        atomicAdd(S.mode_count + mode, 1ull);
     }
 }
 
-void asx_launch_pearson_spectral_f32(const AsxDev &P, const float *src, const float *smp, const AsxPeakWs &W, const AsxSpecWs &S,
+void asx_launch_pearson_spectral_f32(const AsxDev &P, const float *src, const float *smp, const AsxPeakWs &W, const AsxSpecWs &S0,
                                      AsxSeg *seg, double *psums, int64_t *lag, double *coef, int32_t *ret, int npairs,
                                      hipStream_t s)
 {
-    if ((size_t)P.band_rows * (size_t)P.M2 >= 16384)
+    AsxSpecWs S = S0;
+    S.N = P.N;
+    if ((size_t)P.band_rows * (size_t)P.M2 >= 16384) {
+        S.nb = ASX_PREP_BLOCKS;
         hipLaunchKernelGGL((k_pearson_prep<ASX_PREP_THREADS, ASX_PREP_BLOCKS>), dim3(ASX_PREP_BLOCKS, npairs), dim3(ASX_PREP_THREADS), 0, s, P.self_dev, src, smp, W, S, seg);
-    else
+    } else {
+        S.nb = 1;
         hipLaunchKernelGGL((k_pearson_prep<256, 1>), dim3(1, npairs), dim3(256), 0, s, P.self_dev, src, smp, W, S, seg);
-    asx_launch_pearson_partial_f32(src, smp, 2 * (size_t)P.N, P.N, P.N, S.seg2, psums, npairs, s);
-    hipLaunchKernelGGL(k_pearson_final_spec, dim3(npairs), dim3(64), 0, s, seg, psums, asx_pearson_blocks(P.N), S.pre, lag, coef, ret);
+    }
+    asx_launch_pearson_partial_spec_f32(src, smp, 2 * (size_t)P.N, P.N, P.N, seg, S, psums, npairs, s);
+    hipLaunchKernelGGL(k_pearson_final_spec, dim3(npairs), dim3(64), 0, s, seg, psums, asx_pearson_blocks(P.N), S, lag, coef, ret);
 }

@@ -229,6 +229,54 @@ __device__ __forceinline__ AsxSeg make_seg(uint32_t peak, uint32_t N)
 }
 
 // ---------------------------------------------------------------------------
+// The spectral Pearson form's decision for one pair (pearson_spectral.hip), from what k_pearson_prep left: the blocks' shares of the window
+// sums (added here in block order: the same bits whoever adds them), r[peak] and the bound on its error.  Pure: every block of
+// k_pearson_partial and k_pearson_final_spec work it out for themselves and agree.
+//   mode   ASX_PM_FAST / CORR / DIRECT;   work = what k_pearson_partial walks: nothing, the wrap-around part, or the segment itself
+// ---------------------------------------------------------------------------
+struct AsxSpecPick {
+    int mode;
+    double n, Sx, Sxx, Sy, Syy, r, bound;
+    AsxSeg work;
+};
+__device__ __forceinline__ AsxSpecPick asx_spec_pick(const AsxSeg s, const double *__restrict__ part, int nb, const double *__restrict__ hdr,
+                                                     double tol, uint32_t N)
+{
+    AsxSpecPick d;
+    d.mode = ASX_PM_DIRECT;
+    d.n = (double)s.len;
+    d.Sx = d.Sxx = d.Sy = d.Syy = d.r = 0.0;
+    d.bound = INFINITY;
+    d.work = s;
+    if (hdr[2] == 0.0) {
+        double v[4];
+        for (int k = 0; k < 4; k++) {
+            double t = part[k];
+            for (int b = 1; b < nb; b++) t += part[b * 4 + k];
+            v[k] = t;
+        }
+        const double n = d.n, Sx = v[0], Sxx = v[1], Sy = v[2], Syy = v[3], rb = hdr[1];
+        d.Sx = Sx; d.Sxx = Sxx; d.Sy = Sy; d.Syy = Syy; d.r = hdr[0];
+        const double A = Sxx - Sx * Sx / n, B = Syy - Sy * Sy / n;
+        if (A > 0.0 && B > 0.0) {
+            // float32 band sums: <= 16 eps relative on a sum of squares, <= 16 eps * sum|x| <= 16 eps sqrt(n Sxx) on a plain sum
+            const double es = 16.0 * 5.9604645e-8;
+            const double dSx = es * sqrt(n * Sxx), dSy = es * sqrt(n * Syy);
+            const double dC = rb + (fabs(Sy) * dSx + fabs(Sx) * dSy) / n;
+            const double dA = es * Sxx + 2.0 * fabs(Sx) / n * dSx, dB = es * Syy + 2.0 * fabs(Sy) / n * dSy;
+            d.bound = dC / sqrt(A * B) + 0.5 * (dA / A + dB / B); // |coefficient| <= 1
+            if (d.bound <= tol) {
+                if (s.peak < N) d.mode = ASX_PM_FAST;
+                else if (N - s.len < s.len) d.mode = ASX_PM_CORR; // |lag| products instead of L
+            }
+        }
+    }
+    if (d.mode == ASX_PM_FAST) d.work.len = 0;
+    else if (d.mode == ASX_PM_CORR) { d.work.src_off = s.peak; d.work.smp_off = 0; d.work.len = N - s.len; }
+    return d;
+}
+
+// ---------------------------------------------------------------------------
 // Pearson partial statistics and their exact pairwise merge (Chan et al.); see k_pearson_partial
 // ---------------------------------------------------------------------------
 struct PStat {

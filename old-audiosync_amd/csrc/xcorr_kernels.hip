@@ -1026,17 +1026,20 @@ __global__ __launch_bounds__(ASX_THREADS) void k_refine_pick(const AsxDev *__res
 // bit-identical Mxx, Myy, Cxy and therefore exactly +-1.0 (tests/test_cross_correlation.c:29).
 // ---------------------------------------------------------------------------
 // (PStat, pstat_merge, pstat_wave_merge: xcorr_dev.h -- shared with pearson_spectral.hip)
-template <typename TIn>
+template <typename TIn, bool SPEC>
 __global__ __launch_bounds__(ASX_THREADS) void k_pearson_partial(const TIn *__restrict__ src,
                                                                   const TIn *__restrict__ smp,
                                                                   size_t src_pitch, size_t smp_pitch,
                                                                   uint32_t basis_len,
                                                                   const AsxSeg *__restrict__ seg,
-                                                                  double *__restrict__ psums)
+                                                                  double *__restrict__ psums, AsxSpecWs V)
 {
     __shared__ double red[6][ASX_THREADS / 64];
     const size_t pair = blockIdx.y;
-    const AsxSeg s = seg[pair];
+    AsxSeg s = seg[pair];
+    // SPEC (the spectral Pearson form): what this pair still needs read -- nothing, its wrap-around part, or its segment -- follows from
+    // the sums k_pearson_prep left; every block works that out for itself (pair-uniform: scalar loads and arithmetic)
+    if constexpr (SPEC) s = asx_spec_pick(s, V.part + pair * (size_t)(V.nb * 4), V.nb, V.hdr + pair * ASX_SPEC_HDR, V.tol, V.N).work;
     // gridDim.x partial blocks per pair (asx_pearson_blocks: by the basis length alone); the final kernel merges
     // exactly gridDim.x entries
     const uint32_t chunk = (basis_len + gridDim.x - 1) / gridDim.x;
@@ -1509,17 +1512,17 @@ void asx_launch_pearson_f32(const float *src, const float *smp, size_t src_pitch
                             double *coef, int32_t *ret, int npairs, hipStream_t s)
 {
     const unsigned nb = asx_pearson_blocks(basis_len);
-    hipLaunchKernelGGL(k_pearson_partial<float>, dim3(nb, npairs), dim3(ASX_THREADS), 0, s,
-                       src, smp, src_pitch, smp_pitch, basis_len, seg, psums);
+    hipLaunchKernelGGL((k_pearson_partial<float, false>), dim3(nb, npairs), dim3(ASX_THREADS), 0, s,
+                       src, smp, src_pitch, smp_pitch, basis_len, seg, psums, AsxSpecWs{});
     hipLaunchKernelGGL(k_pearson_final, dim3(npairs), dim3(64), 0, s, seg, psums, nb, lag, coef, ret);
 }
 
-void asx_launch_pearson_partial_f32(const float *src, const float *smp, size_t src_pitch, size_t smp_pitch,
-                                    uint32_t basis_len, const AsxSeg *seg, double *psums, int npairs, hipStream_t s)
+void asx_launch_pearson_partial_spec_f32(const float *src, const float *smp, size_t src_pitch, size_t smp_pitch, uint32_t basis_len,
+                                         const AsxSeg *seg, const AsxSpecWs &S, double *psums, int npairs, hipStream_t s)
 {
     const unsigned nb = asx_pearson_blocks(basis_len);
-    hipLaunchKernelGGL(k_pearson_partial<float>, dim3(nb, npairs), dim3(ASX_THREADS), 0, s,
-                       src, smp, src_pitch, smp_pitch, basis_len, seg, psums);
+    hipLaunchKernelGGL((k_pearson_partial<float, true>), dim3(nb, npairs), dim3(ASX_THREADS), 0, s,
+                       src, smp, src_pitch, smp_pitch, basis_len, seg, psums, S);
 }
 
 void asx_launch_pearson_f64(const double *src, const double *smp, size_t src_pitch, size_t smp_pitch,
@@ -1527,8 +1530,8 @@ void asx_launch_pearson_f64(const double *src, const double *smp, size_t src_pit
                             double *coef, int32_t *ret, int npairs, hipStream_t s)
 {
     const unsigned nb = asx_pearson_blocks(basis_len);
-    hipLaunchKernelGGL(k_pearson_partial<double>, dim3(nb, npairs), dim3(ASX_THREADS), 0, s,
-                       src, smp, src_pitch, smp_pitch, basis_len, seg, psums);
+    hipLaunchKernelGGL((k_pearson_partial<double, false>), dim3(nb, npairs), dim3(ASX_THREADS), 0, s,
+                       src, smp, src_pitch, smp_pitch, basis_len, seg, psums, AsxSpecWs{});
     hipLaunchKernelGGL(k_pearson_final, dim3(npairs), dim3(64), 0, s, seg, psums, nb, lag, coef, ret);
 }
 
