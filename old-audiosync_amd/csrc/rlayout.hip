@@ -453,6 +453,9 @@ template <int NITEMS, int H, int NT> __device__ __forceinline__ int rcol_item_of
     if (!ASX_SPECIAL_LAST || !own_wave) return t < NITEMS ? t : -1;
     return t < NITEMS - H ? t + H : t >= NT - H ? t - (NT - H) : -1;
 }
+#ifndef ASX_INV_WU
+#define ASX_INV_WU 1 // k_inv_cols_r: see WU_FRONT
+#endif
 #ifndef ASX_RCOL_LOADS
 #define ASX_RCOL_LOADS 5 // row-pair pieces (two 16-byte loads each) a thread keeps in flight
 #endif
@@ -672,6 +675,13 @@ __global__ __launch_bounds__(NT, 4) void k_inv_cols_r(const RArgs P, const float
         const int g = e & (H - 1), v = e >> logH;  // v = u_b in [0, MB/2)
         const int ub = v, ubp = v == 0 ? MB / 2 : MB - v; // first rows of the two butterflies' row sets
         const float2 *ca = in + (size_t)ub * M2 + c0 + 2 * g, *cb = in + (size_t)ubp * M2 + c0 + 2 * g;
+        // The tangling twiddle w_{2 M1}^u_b = w_F^(u_b M2).  WU_FRONT: asked for IN FRONT of the rows (vmcnt completes in order) and used by
+        // both branches below (u_b = 0: exactly 1), which keeps the compiler from sinking the look-up into the one branch that needs it,
+        // behind the rows, where its second table value was only issued when the rows had arrived: 0.317 -> 0.3055 ms at 600 rows.  The
+        // 400- and 300-row instances lose 1 - 1.6 % with it (profiles/r5_experiments/23_*) and keep the look-up where it was.
+        constexpr bool WU_FRONT = ASX_INV_WU && M1 == 600;
+        float2 wu_all = make_float2(1.f, 0.f);
+        if constexpr (WU_FRONT) wu_all = tw_F(P, (uint32_t)ub * (uint32_t)M2);
         Cx2 A[RL], B[RL];
         static_for<0, RL>([&](auto TT) __attribute__((always_inline)) {
             constexpr int t = decltype(TT)::value;
@@ -682,7 +692,7 @@ __global__ __launch_bounds__(NT, 4) void k_inv_cols_r(const RArgs P, const float
         });
         Cx2 za[RL], zb[RL];
         if (v != 0) {
-            const float2 wu = tw_F(P, (uint32_t)ub * (uint32_t)M2); // w_{2 M1}^u_b = w_F^(u_b M2)
+            const float2 wu = WU_FRONT ? wu_all : tw_F(P, (uint32_t)ub * (uint32_t)M2);
             static_for<0, RL>([&](auto TT) __attribute__((always_inline)) {
                 constexpr int t = decltype(TT)::value;
                 const Cx2 b = B[RL - 1 - t];
@@ -703,7 +713,8 @@ __global__ __launch_bounds__(NT, 4) void k_inv_cols_r(const RArgs P, const float
                 if constexpr (t != 0) b = A[RL - t];
                 const Cx2 S = Cx2{ A[t].re + b.re, A[t].im - b.im };
                 const Cx2 D = Cx2{ A[t].re - b.re, A[t].im + b.im };
-                za[t] = S + mul_pos_i(mul_root<2 * RL, t, true>(D));
+                if constexpr (WU_FRONT) za[t] = S + mul_pos_i(mul_root<2 * RL, t, true>(mulwc(D, wu_all))); // wu_all = w_F^0 = 1 here
+                else za[t] = S + mul_pos_i(mul_root<2 * RL, t, true>(D));
             });
             static_for<0, RL>([&](auto TT) __attribute__((always_inline)) {
                 constexpr int t = decltype(TT)::value;
