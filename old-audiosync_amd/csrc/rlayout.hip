@@ -150,10 +150,11 @@ __device__ __forceinline__ void st_f2(float2 *p, float2 v, bool nt)
 // bit 0 = the block's tw_step / leg entries BEFORE the row loads (the barrier in front of the load phase's arithmetic then waits for an
 // L2 round trip that overlaps the HBM loads instead of following them); bit 1 = the twiddles of the two-half form's store phase at
 // the top of the kernel instead of behind its last barrier
-// Measured (profiles/r5_experiments/19_*, four alternating rounds): bit 1 rows 0.931 -> 0.918 ms (the store phase started with an L2 round
-// trip on the two waves that run it); bit 0 nothing (0.930); both 0.921.  Default: bit 1.
+// Measured (profiles/r5_experiments/19_*, alternating rounds): bit 1 rows 0.931 -> 0.918 ms (the store phase started with an L2 round
+// trip on the two waves that run it); bit 0 nothing (0.930); both 0.921.  Bit 2 (the load steps' w_M2 values in front of the rows, whole
+// steps without a condition): 0.946 -> 0.912 ms on top of bit 1, 0.939 -> 0.904 at N = 960 000.  Default: bits 1 and 2.
 #ifndef ASX_ROWS_EARLY
-#define ASX_ROWS_EARLY 2
+#define ASX_ROWS_EARLY 6
 #endif
 #ifndef ASX_ROWSR_WAVES
 #define ASX_ROWSR_WAVES 4 // waves per SIMD the register allocation must allow: 8 blocks of 2 waves per CU
@@ -235,13 +236,24 @@ __global__ __launch_bounds__(TWO ? 2 * NT : NT, ASX_ROWSR_WAVES) void k_rows_r(c
         tail_lo = P.tw_lo[p & (ASX_TW_LO - 1u)];
         tail_hi = P.tw_hi[p >> ASX_TW_LOG];
     }
+    // (bit 2 of ASX_ROWS_EARLY: the two-half form's w_M2^(2q), w_M2^(2q+1) of every load step asked for HERE, in front of the rows, instead
+    // of inside the step behind the barrier -- a table load and the wait for it between the arrival of the rows and their first use)
+    float4 w2pre[TWO ? WSTEPS : 1];
+    if constexpr (TWO && (ASX_ROWS_EARLY & 4) != 0) {
+        static_for<0, WSTEPS>([&](auto I) __attribute__((always_inline)) {
+            constexpr int i = decltype(I)::value;
+            const int q = tid + i * NTB;
+            w2pre[I] = make_float4(1.f, 0.f, 1.f, 0.f);
+            if ((i + 1) * NTB <= HALF || q < HALF) w2pre[I] = *reinterpret_cast<const float4 *>(P.tw2 + 2 * q);
+        });
+    }
     // every row load of the thread first; the twiddle lookups below overlap them
     float4 lx[WSTEPS], ly[WSTEPS], lx2[TWO ? WSTEPS : 1], ly2[TWO ? WSTEPS : 1];
     {
         const float2 *gx = cx + row, *gy = cy + row;
         static_for<0, WSTEPS>([&](auto I) __attribute__((always_inline)) {
             const int q = tid + decltype(I)::value * NTB;
-            if (q < HALF) {
+            if (((ASX_ROWS_EARLY & 4) && (decltype(I)::value + 1) * NTB <= HALF) || q < HALF) { // (a whole step inside the row: no condition)
                 lx[I] = ld_f4(gx + 2 * q, ASX_RNT & 4);
                 ly[I] = ld_f4(gy + 2 * q, ASX_RNT & 4);
                 if constexpr (TWO) {
@@ -276,7 +288,7 @@ __global__ __launch_bounds__(TWO ? 2 * NT : NT, ASX_ROWSR_WAVES) void k_rows_r(c
     static_for<0, WSTEPS>([&](auto I) __attribute__((always_inline)) {
         constexpr int i = decltype(I)::value;
         const int q = tid + i * NTB;
-        if (q < HALF) {
+        if (((ASX_ROWS_EARLY & 4) && (i + 1) * NTB <= HALF) || q < HALF) {
             const float2 wa0 = cmul(twa, tw_step[i]), wa1 = cmul(wa0, wk1);
             const Cx2 c0 = mulw(Cx2{ v2f{ lx[I].x, ly[I].x }, v2f{ lx[I].y, ly[I].y } }, wa0);
             const Cx2 c1 = mulw(Cx2{ v2f{ lx[I].z, ly[I].z }, v2f{ lx[I].w, ly[I].w } }, wa1);
@@ -288,7 +300,7 @@ __global__ __launch_bounds__(TWO ? 2 * NT : NT, ASX_ROWSR_WAVES) void k_rows_r(c
                 const float2 wb0 = cmul(wa0, wh), wb1 = cmul(wa1, wh);
                 const Cx2 d0 = mulw(Cx2{ v2f{ lx2[I].x, ly2[I].x }, v2f{ lx2[I].y, ly2[I].y } }, wb0);
                 const Cx2 d1 = mulw(Cx2{ v2f{ lx2[I].z, ly2[I].z }, v2f{ lx2[I].w, ly2[I].w } }, wb1);
-                const float4 w2 = *reinterpret_cast<const float4 *>(P.tw2 + 2 * q); // w_M2^(2q), w_M2^(2q+1)
+                const float4 w2 = (ASX_ROWS_EARLY & 4) ? w2pre[I] : *reinterpret_cast<const float4 *>(P.tw2 + 2 * q); // w_M2^(2q), w_M2^(2q+1)
                 lds_put(base + 2 * q, c0 + d0);
                 lds_put(base + 2 * q + 1, c1 + d1);
                 lds_put(base + NS + 2 * q, mulw(c0 - d0, make_float2(w2.x, w2.y)));
