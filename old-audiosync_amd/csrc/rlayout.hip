@@ -152,9 +152,11 @@ __device__ __forceinline__ void st_f2(float2 *p, float2 v, bool nt)
 // the top of the kernel instead of behind its last barrier
 // Measured (profiles/r5_experiments/19_*, alternating rounds): bit 1 rows 0.931 -> 0.918 ms (the store phase started with an L2 round
 // trip on the two waves that run it); bit 0 nothing (0.930); both 0.921.  Bit 2 (the load steps' w_M2 values in front of the rows, whole
-// steps without a condition): 0.946 -> 0.912 ms on top of bit 1, 0.939 -> 0.904 at N = 960 000.  Default: bits 1 and 2.
+// steps without a condition): 0.946 -> 0.912 ms on top of bit 1, 0.939 -> 0.904 at N = 960 000.  Bit 3 (EVERY table look-up of the thread in
+// front of its row loads): 480-point rows 0.771 -> 0.742 ms per 1024 pairs of N = 144 000, 0.928 -> 0.899 at 288 000; two-half form 0.917 -> 0.911.
+// Default: bits 1, 2 and 3.
 #ifndef ASX_ROWS_EARLY
-#define ASX_ROWS_EARLY 6
+#define ASX_ROWS_EARLY 14
 #endif
 #ifndef ASX_ROWSR_WAVES
 #define ASX_ROWSR_WAVES 4 // waves per SIMD the register allocation must allow: 8 blocks of 2 waves per CU
@@ -220,10 +222,13 @@ __global__ __launch_bounds__(TWO ? 2 * NT : NT, ASX_ROWSR_WAVES) void k_rows_r(c
             W.cand_n[pair] = 0;
         }
     }
+    // bit 3 of ASX_ROWS_EARLY (see the row loads below): -3 ... -4 % for 480-point rows, -0.7 % for the two-half form, +0.6 % for 1200-point
+    // rows in one piece, which keep the old order (profiles/r5_experiments/19_*)
+    constexpr bool LOOKUPS_FIRST = (ASX_ROWS_EARLY & 8) != 0 && (TWO || NS != 1200);
     const bool is_step = tid < WSTEPS, is_leg = tid >= NTB - R0;
     static_assert(WSTEPS <= NTB - R0, "the threads that fill tw_step and leg are different threads");
     float2 pre_lo = make_float2(1.f, 0.f), pre_hi = pre_lo;
-    if ((ASX_ROWS_EARLY & 1) && (is_step || is_leg)) {
+    if ((LOOKUPS_FIRST || (ASX_ROWS_EARLY & 1)) && (is_step || is_leg)) {
         const uint32_t p = is_step ? k1 * (uint32_t)(2 * NTB * tid) : k1 * (uint32_t)(Q0 * (tid - (NTB - R0)));
         pre_lo = P.tw_lo[p & (ASX_TW_LO - 1u)];
         pre_hi = P.tw_hi[p >> ASX_TW_LOG];
@@ -247,9 +252,11 @@ __global__ __launch_bounds__(TWO ? 2 * NT : NT, ASX_ROWSR_WAVES) void k_rows_r(c
             if ((i + 1) * NTB <= HALF || q < HALF) w2pre[I] = *reinterpret_cast<const float4 *>(P.tw2 + 2 * q);
         });
     }
-    // every row load of the thread first; the twiddle lookups below overlap them
+    // The row loads.  Bit 3 of ASX_ROWS_EARLY: issued BEHIND every table look-up of the thread (they used to come first, "the look-ups
+    // overlap them" -- but vmcnt completes in order: a look-up issued behind the rows is not usable before the rows have arrived, and the
+    // tw_step / leg threads then started an L2 round trip of their own in front of the block's barrier)
     float4 lx[WSTEPS], ly[WSTEPS], lx2[TWO ? WSTEPS : 1], ly2[TWO ? WSTEPS : 1];
-    {
+    auto issue_row_loads = [&]() __attribute__((always_inline)) {
         const float2 *gx = cx + row, *gy = cy + row;
         static_for<0, WSTEPS>([&](auto I) __attribute__((always_inline)) {
             const int q = tid + decltype(I)::value * NTB;
@@ -262,13 +269,17 @@ __global__ __launch_bounds__(TWO ? 2 * NT : NT, ASX_ROWSR_WAVES) void k_rows_r(c
                 }
             }
         });
-    }
-    if (is_step) {
-        // ... times 1/2: k_fwd_cols_r stores 2 C (its untangling without the halving)
-        const float2 t = (ASX_ROWS_EARLY & 1) ? cmul(pre_lo, pre_hi) : tw_F(P, k1 * (uint32_t)(2 * NTB * tid));
-        tw_step[tid] = make_float2(0.5f * t.x, 0.5f * t.y);
-    }
-    if (is_leg) { const int t = tid - (NTB - R0); leg[t] = (ASX_ROWS_EARLY & 1) ? cmul(pre_lo, pre_hi) : tw_F(P, k1 * (uint32_t)(Q0 * t)); }
+    };
+    if constexpr (!LOOKUPS_FIRST) issue_row_loads();
+    auto publish_step_and_leg = [&]() __attribute__((always_inline)) {
+        if (is_step) {
+            // ... times 1/2: k_fwd_cols_r stores 2 C (its untangling without the halving)
+            const float2 t = (LOOKUPS_FIRST || (ASX_ROWS_EARLY & 1)) ? cmul(pre_lo, pre_hi) : tw_F(P, k1 * (uint32_t)(2 * NTB * tid));
+            tw_step[tid] = make_float2(0.5f * t.x, 0.5f * t.y);
+        }
+        if (is_leg) { const int t = tid - (NTB - R0); leg[t] = (LOOKUPS_FIRST || (ASX_ROWS_EARLY & 1)) ? cmul(pre_lo, pre_hi) : tw_F(P, k1 * (uint32_t)(Q0 * t)); }
+    };
+    if constexpr (!LOOKUPS_FIRST) publish_step_and_leg();
     const float2 twa = tw_F(P, k1 * (uint32_t)(2 * tid < NS ? 2 * tid : 0)); // w_F^(k1 * 2 tid)
     const float2 wk1 = tw_F(P, k1);
     const float2 wh = TWO ? tw_F(P, k1 * (uint32_t)NS) : make_float2(1.f, 0.f); // w_F^(k1 n): from c[j] to c[j + n]
@@ -280,6 +291,7 @@ __global__ __launch_bounds__(TWO ? 2 * NT : NT, ASX_ROWSR_WAVES) void k_rows_r(c
     const int ul = lane / LPU, jl = lane - ul * LPU;
     const int j1c = jl < R2 ? jl : 0;
     const float2 s1w1 = P.tw2[TWS * K1.twmul * j1c], s1w4 = P.tw2[TWS * (R1 > 4 ? 4 : 1) * K1.twmul * j1c];
+    if constexpr (LOOKUPS_FIRST) { issue_row_loads(); publish_step_and_leg(); }
     RSTAMP(0, task, 0);
 #ifdef ASX_STAMPS
     if (P.stamps && P.stamp_kernel == 0 && threadIdx.x == 0) { P.stamps[(size_t)task * 8 + 6] = t_entry; P.stamps[(size_t)task * 8 + 7] = w_entry; }
