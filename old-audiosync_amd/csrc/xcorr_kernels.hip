@@ -1026,6 +1026,11 @@ __global__ __launch_bounds__(ASX_THREADS) void k_refine_pick(const AsxDev *__res
 // bit-identical Mxx, Myy, Cxy and therefore exactly +-1.0 (tests/test_cross_correlation.c:29).
 // ---------------------------------------------------------------------------
 // (PStat, pstat_merge, pstat_wave_merge: xcorr_dev.h -- shared with pearson_spectral.hip)
+// steps of k_pearson_partial's loop whose loads are in flight together (0 = one step at a time, as it was): the direct form 0.200 -> 0.190 ms
+// per 124 pairs of N = 1 440 000, the spectral form's remainder 0.090 -> 0.087 (profiles/r5_experiments/24_*); the same additions in the same order
+#ifndef ASX_PEARSON_DEEP
+#define ASX_PEARSON_DEEP 4
+#endif
 template <typename TIn, bool SPEC>
 __global__ __launch_bounds__(ASX_THREADS) void k_pearson_partial(const TIn *__restrict__ src,
                                                                   const TIn *__restrict__ smp,
@@ -1056,7 +1061,12 @@ __global__ __launch_bounds__(ASX_THREADS) void k_pearson_partial(const TIn *__re
     const TIn *y = smp + pair * smp_pitch + s.smp_off;
     uint64_t i = lo + 4u * threadIdx.x;
     double px = 0, py = 0; // pivots: the first element this thread meets
+#if ASX_PEARSON_DEEP
+    // (taken from the first 16-byte load below when the thread has one: a scalar load and the wait for it in front of the loop otherwise)
+    if (i < hi && !(i + 3 < hi)) { px = (double)x[i]; py = (double)y[i]; }
+#else
     if (i < hi) { px = (double)x[i]; py = (double)y[i]; }
+#endif
     double sx = 0, sy = 0, sxy = 0, sxx = 0, syy = 0;
     uint32_t cnt = 0;
     auto add = [&](double a, double b) {
@@ -1071,6 +1081,31 @@ __global__ __launch_bounds__(ASX_THREADS) void k_pearson_partial(const TIn *__re
     // four consecutive elements per lane and step: 16-byte loads (the segments start at any element,
     // so the vector type only promises element alignment), then the few elements that are left
     typedef TIn vec4u __attribute__((ext_vector_type(4), aligned(sizeof(TIn))));
+    auto ld4 = [&](const TIn *p) __attribute__((always_inline)) {
+        return (ASX_NT & 4) ? __builtin_nontemporal_load(reinterpret_cast<const vec4u *>(p)) : *reinterpret_cast<const vec4u *>(p);
+    };
+#if ASX_PEARSON_DEEP
+    // ASX_PEARSON_DEEP steps at a time: their 2 * ASX_PEARSON_DEEP loads in flight together, then the same additions in the same order (the
+    // loop used to wait for each step's two loads before it issued the next step's: 16 memory round trips per block, one after the other)
+    {
+        bool first = i + 3 < hi;
+        constexpr uint32_t STEP = 4u * ASX_THREADS;
+        for (; i + 3 + (uint64_t)(ASX_PEARSON_DEEP - 1) * STEP < hi; i += (uint64_t)ASX_PEARSON_DEEP * STEP) {
+            vec4u a[ASX_PEARSON_DEEP], b[ASX_PEARSON_DEEP];
+#pragma unroll
+            for (int u = 0; u < ASX_PEARSON_DEEP; u++) { a[u] = ld4(x + i + (uint64_t)u * STEP); b[u] = ld4(y + i + (uint64_t)u * STEP); }
+            if (first) { px = (double)a[0].x; py = (double)b[0].x; first = false; }
+#pragma unroll
+            for (int u = 0; u < ASX_PEARSON_DEEP; u++) {
+                add((double)a[u].x, (double)b[u].x);
+                add((double)a[u].y, (double)b[u].y);
+                add((double)a[u].z, (double)b[u].z);
+                add((double)a[u].w, (double)b[u].w);
+            }
+        }
+        if (first) { px = (double)x[i]; py = (double)y[i]; } // fewer than ASX_PEARSON_DEEP whole steps: the step loop below meets it first
+    }
+#endif
     for (; i + 3 < hi; i += 4u * ASX_THREADS) {
         const vec4u a = (ASX_NT & 4) ? __builtin_nontemporal_load(reinterpret_cast<const vec4u *>(x + i)) : *reinterpret_cast<const vec4u *>(x + i);
         const vec4u b = (ASX_NT & 4) ? __builtin_nontemporal_load(reinterpret_cast<const vec4u *>(y + i)) : *reinterpret_cast<const vec4u *>(y + i);
