@@ -660,7 +660,10 @@ __global__ __launch_bounds__(NT, 4) void k_inv_cols_r(const RArgs P, const float
         // the same length -- and, started together, stay in step: both wait for memory, then both compute.  The blocks of the FIRST
         // generation start half a block's life apart, by the parity of their position in the launch order (the split that measured
         // best); later generations inherit the offset.  0.370 -> 0.349 ms at 600 rows, -3 .. -6 % at 400 (rows and
-        // forward columns: nothing, profiles/r5_experiments/05_*).  Speed only.
+        // forward columns: nothing, profiles/r5_experiments/05_*).  Speed only.  (What it staggers is not the two blocks of a CU -- those are
+        // 256 apart in launch order, same parity -- but HALF THE CHIP against the other half: a read-only kernel whose blocks all take the
+        // same time otherwise loads in step and computes in step chip-wide, and the memory system idles between the bursts.  On the round's
+        // final kernel: 0.373 ms without, 0.301 with; more phases or other lengths: the same, profiles/r5_experiments/25_*.)
         constexpr bool TWO_PER_CU = (size_t)M1 * T * 8 > 40 * 1024; // 600- and 400-row tiles; four blocks of 300 rows: measured 1.5 % slower
         const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y;
         if (TWO_PER_CU && lin < 512u && (lin & 1u))
