@@ -16,10 +16,11 @@
 //
 // r[peak] is the float32 transforms' value (k_inv_cols_r leaves the SIGNED value of each tile's best lag, AsxPeakWs::tile_peak),
 // or the exact one when the pair's near-ties were re-evaluated (k_refine_dots).  Its error is bounded by the SAME bound B that
-// guards the lag (asx_internal.h); the band sums are float32 sums of 128 terms (a tree: relative error <= 16 eps).  k_pearson_prep
-// turns both into a bound on the coefficient's error and keeps the spectral form only when that bound is below `tol` (1e-5,
-// north_star's tolerance); otherwise -- quiet windows of a loud track, offsets, short segments -- the pair takes the reference's
-// own reduction (k_pearson_partial over the segment, ASX_PM_DIRECT).  Float32 inputs on real-column plans only; the double ABI,
+// guards the lag (asx_internal.h); the band sums are float32 sums of 128 terms (a tree: relative error <= 16 eps).  asx_spec_pick
+// (xcorr_dev.h; every block of k_pearson_partial and k_pearson_final_spec runs it on what k_pearson_prep left) turns both into a
+// bound on the coefficient's error and keeps the spectral form only when that bound is below `tol` (1e-5, north_star's tolerance);
+// otherwise -- quiet windows of a loud track, offsets, short segments -- the pair takes the reference's own reduction
+// (k_pearson_partial over the segment, ASX_PM_DIRECT).  Float32 inputs on real-column plans only; the double ABI,
 // the second look and the packed-sample kernels keep the direct reduction.
 //
 // Per pair the pass reads: FAST <= 2 band edges of each track (<= 0.3 MB at N = 1 440 000 instead of 11.5 MB); CORR + 8 |lag|
