@@ -664,9 +664,13 @@ __global__ __launch_bounds__(NT, 4) void k_inv_cols_r(const RArgs P, const float
         // 256 apart in launch order, same parity -- but HALF THE CHIP against the other half: a read-only kernel whose blocks all take the
         // same time otherwise loads in step and computes in step chip-wide, and the memory system idles between the bursts.  On the round's
         // final kernel: 0.373 ms without, 0.301 with; more phases or other lengths: the same, profiles/r5_experiments/25_*.)
-        constexpr bool TWO_PER_CU = (size_t)M1 * T * 8 > 40 * 1024; // 600- and 400-row tiles; four blocks of 300 rows: measured 1.5 % slower
+        // The first generation = the blocks resident at once: two per CU for 600- and 400-row tiles, four for 300-row tiles.  (Round 5 had
+        // left the 300-row instance alone -- with the FIRST 512 of its 1024 resident blocks treated that way it was 1.5 % slower; with the
+        // whole first generation: 0.310 -> 0.278 ms per 1024 pairs of N = 144 000, profiles/r5_experiments/25_*.)
+        constexpr bool TWO_PER_CU = (size_t)M1 * T * 8 > 40 * 1024;
+        constexpr unsigned FIRST_GEN = TWO_PER_CU ? 512u : 1024u;
         const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y;
-        if (TWO_PER_CU && lin < 512u && (lin & 1u))
+        if (gridDim.x * gridDim.y > FIRST_GEN && lin < FIRST_GEN && (lin & 1u)) // (a launch of one generation has nobody to inherit the offset)
             for (unsigned i = 0; i < (unsigned)(M1 * 27 / 64 / 2); i += 16) __builtin_amdgcn_s_sleep(16); // half a block's life; 64 cycles per unit
     }
     const double shift = W.shift ? W.shift[pair] : 0.0; // non-zero only in the second look (asx_api.hip)
