@@ -42,6 +42,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 BYTES_PER_FRAME = 52             # A(N) = 52*N bytes per cross-correlation
+COEF_TOL = 1e-5                  # BASELINE.json north_star: Pearson coefficient within 1e-5 of the reference's
 ALGO_SHARE = {"fwd_cols": 28, "rows": 16, "inv_cols": 0, "pearson": 8}   # DESIGN.md "Algorithmic bytes"
 FAMILIES = ("fwd_cols", "rows", "inv_cols", "finalize", "pearson", "total")
 CONFIG4_BATCH, CONFIG4_N = 8192, 480000
@@ -202,6 +203,15 @@ def cpu_baseline(sample_len, point_seconds=3.0, sweeps=3):
                       "sweeps over three worker counts, best point; taken before the first GPU call; backend %s" %
                       (best["sweeps"][0]["calls"], sample_len, best["workers"], distinct, point_seconds, sweeps,
                        "FFTW3 (dlopen libfftw3.so.3)" if backend == "fftw3" else "oracle/fft64.c (no libfftw3 on this node)")}
+
+
+def oracle_pair0(sample_len, noise_shift):
+    """cpu_baseline leg only: the oracle's (ret, lag, coefficient) for pair 0 of the bench workload -- oracle.synth_pair is the host
+    twin of k_synth, bit for bit (tests/test_gpu_parity.py::test_device_generator_matches_the_oracle's)"""
+    import oracle
+    src, smp, true_lag = oracle.synth_pair(SEED, 0, sample_len, noise_shift)
+    ret, lag, coef = oracle.cross_correlation(src, smp)
+    return {"ret": int(ret), "lag": int(lag), "coefficient": float(coef), "planted_lag": int(true_lag)}
 
 
 # --------------------------------------------------------------------------------------------------
@@ -425,9 +435,15 @@ def dry_run(args):
         report[name] = {"total": total, "shard": [start, count]}
     t = torch.tensor([1.0 if ok else 0.0])
     dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    # the per-rank record of the GPU run (run_rank: `per_rank`), with fabricated numbers: the same object gather
+    per_rank = [None] * world
+    dist.all_gather_object(per_rank, {"rank": rank, "pairs": report["headline"]["shard"][1], "ms_per_step": 1.0 + rank,
+                                      "kernel_ms_per_step": {k: 0.1 * (rank + 1) for k in FAMILIES}})
     if rank == 0:
         width4 = (CONFIG4_BATCH + world - 1) // world
+        base = load_baseline_line(args.baseline_json)
         print(json.dumps({"dry_run": True, "n_gpus": world, "world_size_seen": dist.get_world_size(), "backend": "gloo",
+                          "per_rank": per_rank, "baseline_seen": None if base is None else base.get("n_gpus"),
                           "results_ok": bool(t.item() == 1.0), "shards_rank0": report, "scaling": "weak",
                           "config4": {"scaling": "strong", "speedup_basis": CONFIG4_SPEEDUP_BASIS, "n_gpus": world,
                                       "pairs_total": CONFIG4_BATCH, "pairs_per_gpu": report["config4"]["shard"][1],
@@ -488,22 +504,57 @@ class Workload:
             dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        self.last_dt_local = dt      # this rank's own clock (the line reports the maximum over ranks; `per_rank` keeps each)
         if self.multi:
             t = torch.tensor([dt], dtype=torch.float64, device=self.d_lag.device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         return dt
 
-    def verify(self):
+    def verify(self, oracle0=None):
         """one more step into cleared buffers; every rank's slice of what the gather delivered must equal that
-        rank's planted delays (gathered separately), ret all zero"""
+        rank's planted delays (gathered separately), ret all zero.  The COEFFICIENT the timed path produced (the spectral
+        Pearson form on real-column plans) is checked too: against the direct reduction of
+        src/cross_correlation.c:74-116 on every pair of this rank (one more step with asx_plan_set_pearson(plan, 0), compared
+        on the device, tolerance COEF_TOL = north_star's 1e-5) and, on rank 0, against the oracle's answer for pair 0 that the
+        cpu_baseline leg left (`oracle0`).  -> (ok, {"coef_max_delta", "coef_oracle_delta", ...})"""
         torch, dist = self.torch, self.dist
+        spectral = self.plan.layout == "real-column" and os.environ.get("ASX_PEARSON") != "direct"   # the same on every rank
         self.res_buf.zero_()
         if self.multi:
             self.gather_out.zero_()
+        torch.cuda.synchronize()
+        modes0 = self.plan.pearson_modes() if spectral else None
         self.step()
         torch.cuda.synchronize()
         ok = bool(torch.equal(self.d_lag[: self.count], self.d_true[: self.count])) and int(self.d_ret[: self.count].abs().sum()) == 0
+        info = {"coef_tol": COEF_TOL, "coef_max_delta": None, "coef_oracle_delta": None, "coef_pairs_compared": 0}
+        if spectral:   # this rank's pairs of ONE step by the form that produced their coefficient: [spectral, spectral + wrap-around part, direct]
+            info["pearson_modes_per_step"] = [int(b - a) for a, b in zip(modes0, self.plan.pearson_modes())]
+        coef_timed = self.d_coef[: self.count].clone()
+        lag0, ret0 = (int(self.d_lag[0]), int(self.d_ret[0])) if self.count else (None, None)
+        gathered_timed = self.gathered
+        if spectral:
+            gather_keep = self.gather_out.clone() if self.multi else None
+            self.plan.set_pearson(False)
+            self.step()                                   # (every rank: the step carries the gather)
+            torch.cuda.synchronize()
+            self.plan.set_pearson(True)
+            if self.count:
+                delta = float((coef_timed - self.d_coef[: self.count]).abs().max())
+                finite = bool(torch.isfinite(coef_timed).all()) and bool(torch.isfinite(self.d_coef[: self.count]).all())
+                info["coef_max_delta"] = delta
+                info["coef_pairs_compared"] = self.count
+                ok = ok and finite and delta < COEF_TOL
+                ok = ok and bool(torch.equal(self.d_lag[: self.count], self.d_true[: self.count]))
+                self.d_coef[: self.count].copy_(coef_timed)
+            if self.multi:                                # what is checked below is what the TIMED form's step gathered
+                self.gather_out.copy_(gather_keep)
+                self.gathered = gathered_timed
+        if oracle0 is not None and self.start == 0 and self.count:
+            d = abs(float(coef_timed[0]) - oracle0["coefficient"])
+            info["coef_oracle_delta"] = d
+            ok = ok and oracle0["ret"] == ret0 and oracle0["lag"] == lag0 and d < COEF_TOL
         if self.multi:
             dist.all_gather_into_tensor(self.true_out.view(-1), self.d_true)
             torch.cuda.synchronize()
@@ -515,7 +566,13 @@ class Workload:
             t = torch.tensor([1.0 if ok else 0.0], device=self.d_lag.device)
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
             ok = bool(t.item() == 1.0)
-        return ok
+            t = torch.tensor([-1.0 if info["coef_max_delta"] is None else info["coef_max_delta"], float(info["coef_pairs_compared"])],
+                             dtype=torch.float64, device=self.d_lag.device)
+            dist.all_reduce(t[:1], op=dist.ReduceOp.MAX)
+            dist.all_reduce(t[1:], op=dist.ReduceOp.SUM)
+            info["coef_max_delta"] = None if float(t[0]) < 0 else float(t[0])
+            info["coef_pairs_compared"] = int(t[1])
+        return ok, info
 
     def kernel_medians(self, steps, lead=0):
         """per-kernel HIP-event durations of `steps` CONSECUTIVE steps behind `lead` untimed ones (the profiling ring keeps
@@ -559,7 +616,19 @@ def traffic_from_profiles(n, split, group, dom):
             for kname, kv in tj["kernels"].items():
                 if kname.startswith("k_" + dom):
                     return kv["hbm_bytes_per_launch"], "profiles/%s (PMC run of %s, commit %s)" % (name, tj.get("date", "?"), tj.get("commit", "?"))
-    return None, None
+    return None, ("no PMC run on file for this configuration (sample_len %d, split %s, %d pairs per launch, kernel k_%s): "
+                  "tools/traffic.sh collects one" % (n, split, group, dom))
+
+
+def load_baseline_line(path):
+    """--baseline-json: a file holding the JSON line of an earlier run of this bench (normally the 1-GPU one); None if absent"""
+    if not path:
+        return None
+    try:
+        lines = [l for l in open(path).read().splitlines() if l.startswith("{")]
+        return json.loads(lines[-1])
+    except (OSError, ValueError, IndexError):
+        return None
 
 
 def run_rank(args, cpu=None):
@@ -613,9 +682,10 @@ def run_rank(args, cpu=None):
         dt = w.timed(args.steps, args.warmup, pre)
         prof_steps = args.profile_steps or max(20, args.steps)
         med, spread, series = w.kernel_medians(prof_steps, lead=10 if args.profile_steps == 0 else 0)
-        ok = w.verify()
+        dt_local = w.last_dt_local
+        ok, coef_check = w.verify(cpu.get("oracle_pair0") if cpu else None)
         plan_group, plan_split, plan_threads, plan_layout = w.plan.group, w.plan.split, w.plan.threads, w.plan.layout
-        overflows = w.plan.peak_overflows()
+        overflows, w_count = w.plan.peak_overflows(), w.count
         spectral_modes = list(w.plan.pearson_modes()) if plan_layout == "real-column" and os.environ.get("ASX_PEARSON") != "direct" else None
         w.close()
         torch.cuda.empty_cache()
@@ -624,18 +694,32 @@ def run_rank(args, cpu=None):
         if not args.no_config4:
             w4 = Workload(asx, sharding, torch, dist, dev, stream, CONFIG4_N, CONFIG4_BATCH, world, rank, multi, 0, None)
             dt4 = w4.timed(args.steps4, 1)
-            ok4 = w4.verify()
+            dt4_local = w4.last_dt_local
+            ok4, coef_check4 = w4.verify()
             cfg4 = {"metric": "cross-correlations/sec (fixed batch %d x N=%d, strong scaling)" % (CONFIG4_BATCH, CONFIG4_N),
                     "value": CONFIG4_BATCH * args.steps4 / dt4, "unit": "cross-correlations/s", "scaling": "strong",
                     "speedup_basis": CONFIG4_SPEEDUP_BASIS,
                     "n_gpus": world, "steps": args.steps4, "ms_per_step": dt4 / args.steps4 * 1e3,
-                    "pairs_total": CONFIG4_BATCH, "pairs_per_gpu": w4.count, "results_ok": ok4,
+                    "pairs_total": CONFIG4_BATCH, "pairs_per_gpu": w4.count, "results_ok": ok4, "coef_check": coef_check4,
                     "path_frac_of_hbm_roofline": BYTES_PER_FRAME * CONFIG4_N * CONFIG4_BATCH * args.steps4 / dt4 / world / 1e9 / HBM_PEAK_GBS,
                     "workload": "BASELINE configs[3]: %d pairs, N=%d, SNR -6 dB, block-partitioned over %d rank(s), inputs "
                                 "generated on the device per shard (%.1f GB per rank), result all-gather timed" %
                                 (CONFIG4_BATCH, CONFIG4_N, world, 12.0 * CONFIG4_N * w4.count / 1e9)}
             w4.close()
             torch.cuda.empty_cache()
+
+        # Every rank's own numbers, gathered on the CPU (gloo) behind the timed regions: should the first run on
+        # more than one GPU fall short of >= 3.5x / >= 7x, the one JSON line says where -- a slow rank (its kernels), the result
+        # gather (ms_per_step far above kernel_ms_sum on every rank) or the host thread (one rank's ms_per_step alone).
+        per_rank = None
+        if multi:
+            mine = {"rank": rank, "device": torch.cuda.current_device(), "pairs": w_count,
+                    "ms_per_step": dt_local / args.steps * 1e3,
+                    "kernel_ms_per_step": {k: round(v, 4) for k, v in med.items()},
+                    "kernel_ms_sum": round(sum(med[k] for k in ("fwd_cols", "rows", "inv_cols", "finalize", "pearson")), 4),
+                    "config4_ms_per_step": (dt4_local / args.steps4 * 1e3) if not args.no_config4 else None}
+            per_rank = [None] * dist.get_world_size()
+            dist.all_gather_object(per_rank, mine, group=cpu_group)
 
         cfg4c = None
         if not args.no_config4 and not args.no_capi:
@@ -729,9 +813,17 @@ def run_rank(args, cpu=None):
                                     "the timed region)",
                            "parallelism": "pairs sharded over %d GPU(s), one process per GPU, RCCL all_gather of results" % world},
                 "world_size_seen": dist.get_world_size() if multi else 1,
-                "results_ok": ok, "peak_overflows": overflows,
+                "results_ok": ok, "coef_check": coef_check, "pearson_modes": spectral_modes, "peak_overflows": overflows,
                 "roofline": roofline,
             }
+            if per_rank is not None:
+                line["per_rank"] = per_rank
+            base = load_baseline_line(args.baseline_json)
+            if base is not None:
+                # weak scaling: N times the pairs in (ideally) the same time; strong scaling: the same 8192 pairs in 1/N of it
+                line["speedup_vs"] = {"baseline_n_gpus": base.get("n_gpus"), "value": value / base["value"] if base.get("value") else None}
+                if cfg4 is not None and base.get("config4", {}).get("value"):
+                    cfg4["speedup_vs"] = {"baseline_n_gpus": base.get("n_gpus"), "value": cfg4["value"] / base["config4"]["value"]}
             if cfg4 is not None:
                 line["config4"] = cfg4
             if cfg4c is not None:
@@ -768,6 +860,8 @@ def main():
                          "runs (tools/traffic.sh, tools/pmc.sh), where every launch is serialised, pass a small number")
     ap.add_argument("--split", default=None)
     ap.add_argument("--dry-run", action="store_true", help="rank/shard/gather path on CPU with gloo, no GPU")
+    ap.add_argument("--baseline-json", default=None,
+                    help="file with the JSON line of an earlier run (normally --gpus 1): adds `speedup_vs` to the line and to config4")
     ap.add_argument("--mode", default="batched", choices=["batched", "streaming", "single", "capi"],
                     help="batched = the headline workload (default); streaming = BASELINE config 5 "
                          "(growing window 3..30 s, plan reuse); single = config 2 (one pair, latency)")
@@ -785,6 +879,9 @@ def main():
     if int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_cpu:
         # rank 0 at N = 1 only, and FIRST: forked worker processes and a clean machine, before any GPU call
         cpu = cpu_baseline(args.sample_len)
+        # the same leg also leaves the checker's answer for pair 0 of the bench workload (the oracle on the inputs k_synth
+        # generates on the device, about a second); Workload.verify() compares the timed path's lag AND coefficient with it
+        cpu["oracle_pair0"] = oracle_pair0(args.sample_len, args.noise_shift)
     return run_rank(args, cpu)
 
 

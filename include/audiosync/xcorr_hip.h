@@ -69,10 +69,12 @@ asx_plan *asx_plan_create(size_t sample_len, size_t max_batch, int device);
  * "auto" = the planner's cost model (tuned table for the reference's six lengths).
  * $ASX_SPLIT supplies the value when the argument is NULL or "". */
 asx_plan *asx_plan_create_ex(size_t sample_len, size_t max_batch, int device, const char *split);
-/* "measure" plans only, once, at their first asx_xcorr_batch_f32_dev call: the forward column kernel is timed against the
- * caller's buffers on two allocations of its output workspaces and the faster set is kept (the kernel runs 2-5 % apart with
- * the physical placement of the buffers it streams together; offsets inside an allocation change nothing).  A few
- * milliseconds and, transiently, a second set of workspaces.  asx_plan_placement: the two times in ms (0 = not measured)
+/* "measure" plans only, once, at their first asx_xcorr_batch_f32_dev call of at least min(group, 8) pairs: the forward column
+ * kernel is timed against the caller's buffers on two allocations of its output workspaces (those of the plan's first stream
+ * lane) and the faster set is kept (the kernel runs 2-5 % apart with the physical placement of the buffers it streams
+ * together; offsets inside an allocation change nothing).  That call allocates, SYNCHRONISES with the device (events on the
+ * caller's stream) and frees: a few milliseconds and, transiently, a second set of workspaces; a call made while its stream is
+ * being captured into a graph does not tune (the next one outside a capture does).  asx_plan_placement: the two times in ms (0 = not measured)
  * and which set was kept (0 = the first, 1 = the second, -1 = not measured).  Plans of every other mode never do this. */
 int asx_plan_placement(asx_plan *plan, double ms[2], int *kept);
 void asx_plan_destroy(asx_plan *plan);
@@ -110,10 +112,15 @@ size_t asx_plan_peak_capacity(const asx_plan *plan);
  *             bound (the one that guards the lag) and that of the float32 band sums are turned into a bound on the
  *             coefficient's error PER PAIR, and a pair whose bound exceeds 1e-5 (quiet windows of a loud track, large
  *             offsets, short segments) takes the direct form by itself.  So: |coefficient - reference's| <= 1e-5 either
- *             way; the spectral form's value is not bit-identical to the direct form's.
+ *             way (the bound is first order in the rounding errors it adds up; measured worst case over the parity and
+ *             fuzz runs: 5e-7); the spectral form's value is not bit-identical to the direct form's.
+ *             ONE OBSERVABLE DIFFERENCE: identical (or exactly negated) segments give exactly +-1.0 only in the direct form
+ *             (the reference's own test asserts `coefficient == 1.0`, tests/test_cross_correlation.c:29); the spectral form
+ *             returns a value clamped to [-1, 1] within 1e-5 of +-1.0 (tests/test_gpu_pearson_spectral.py::
+ *             test_identical_segments_on_the_spectral_path).  asx_plan_set_pearson(plan, 0) restores the reference's bits.
  * cross_correlation(double*) / asx_xcorr_f64 / asx_stream_xcorr always use the direct form on the caller's doubles.
  * asx_plan_pearson_modes: pairs so far that took {spectral, spectral + wrap-around correction, direct} under the spectral
- * setting (synchronises the plan's streams). */
+ * setting (synchronises the DEVICE: batches submitted on a caller's stream are counted too). */
 int asx_plan_set_pearson(asx_plan *plan, int spectral);
 int asx_plan_pearson_modes(asx_plan *plan, uint64_t counts[3]);
 

@@ -130,7 +130,6 @@ struct asx_plan {
     bool exact = true;                 // asx_plan_set_exact: every entry point takes the second look (default)
     bool spectral = false;             // float32 groups take the spectral Pearson form (asx_plan_set_pearson; real-column plans)
     unsigned long long *mode_count = nullptr; // [ASX_PM_NMODES], cumulative over the plan's life
-    bool q_inplace = false;            // k_rows_r writes Q over the rows of C_x it has just read (rlayout only)
     // "measure" plans only: at the first device-resident batch the forward column kernel is timed against the caller's buffers
     // on TWO allocations of its output workspaces and the faster set is kept (tune_placement)
     bool tune_placement = false, placement_done = false;
@@ -287,7 +286,6 @@ static int plan_init(asx_plan *p, size_t N, size_t max_batch, const char *split)
     }
     p->spectral = d.rlayout != 0;
     if (const char *e = getenv("ASX_PEARSON")) p->spectral = p->spectral && strcmp(e, "direct") != 0; // A/B of the two forms
-    if (const char *e = getenv("ASX_Q_INPLACE")) p->q_inplace = atoi(e) != 0 && d.rlayout;
     if (const char *e = getenv("ASX_EXACT")) p->exact = atoi(e) != 0; // initial value of asx_plan_set_exact (A/B of its cost)
     HIP_TRY(hipEventCreateWithFlags(&p->fork, hipEventDisableTiming));
     d.stamps = nullptr;
@@ -504,8 +502,9 @@ extern "C" int asx_plan_pearson_modes(asx_plan *p, uint64_t counts[3])
     if (!dg.ok) return fail("cannot select device %d", p->device);
     counts[0] = counts[1] = counts[2] = 0;
     if (!p->mode_count) return 0;
-    for (int l = 0; l < p->nlanes; l++) HIP_TRY(hipStreamSynchronize(p->lanes[l].stream));
-    HIP_TRY(hipStreamSynchronize(p->stream));
+    // the whole device, as asx_plan_set_exact does: a batch on a caller-supplied stream (asx_xcorr_batch_f32_dev) is on none of the
+    // plan's own streams, and its pairs would be missing from the counts
+    HIP_TRY(hipDeviceSynchronize());
     unsigned long long v[ASX_PM_NMODES];
     HIP_TRY(hipMemcpy(v, p->mode_count, sizeof v, hipMemcpyDeviceToHost));
     for (int i = 0; i < 3; i++) counts[i] = v[i];
@@ -625,7 +624,7 @@ static int run_group(asx_plan *p, const float *d_src, const float *d_smp, const 
     if (prof_mark(p, s, e0 + 0)) return -1;
     asx_launch_fwd_cols(P, d_src, d_smp, W.zxa, W.zya, tk, (int)g, s);
     if (prof_mark(p, s, e0 + 1)) return -1;
-    float2 *q = p->q_inplace ? W.zxa : W.ga;
+    float2 *q = W.ga;
     asx_launch_rows(P, W.zxa, W.zya, q, tk, (int)g, s);
     if (prof_mark(p, s, e0 + 2)) return -1;
     asx_launch_inv_cols(P, q, tk, d_r, (int)g, s);
@@ -760,17 +759,33 @@ static int resolve_overflows(asx_plan *p, const float *f_smp, const TIn *p_src, 
 // and keeps the faster.  The default planning mode never does this.
 static int tune_placement(asx_plan *p, const float *d_src, const float *d_smp, size_t g, hipStream_t s)
 {
+    // (It allocates, synchronises and frees: never inside a stream capture -- a capturing caller keeps the first set, and the next
+    // un-captured batch of >= min(group, 8) pairs tunes.)
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess) (void)hipGetLastError();
+    if (cap != hipStreamCaptureStatusNone) return 0;
     p->placement_done = true;
     const AsxDev &P = p->dev;
     asx_plan::Lane &W = p->lanes[0];
     const size_t mz = ((size_t)p->host.M1 + 1) * (size_t)p->host.M2 * p->group;
-    float2 *alt[2] = { nullptr, nullptr };
+    // whatever leaves this function early gives back the second set and the events (a failing HIP call used to leak them)
+    struct Scratch {
+        float2 *alt[2] = { nullptr, nullptr };
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        bool keep_alt = false;
+        ~Scratch()
+        {
+            if (e0) (void)hipEventDestroy(e0);
+            if (e1) (void)hipEventDestroy(e1);
+            if (!keep_alt) for (float2 *a : alt) if (a) (void)hipFree(a);
+        }
+    } sc;
+    float2 *(&alt)[2] = sc.alt;
     if (hipMalloc((void **)&alt[0], mz * sizeof(float2)) != hipSuccess || hipMalloc((void **)&alt[1], mz * sizeof(float2)) != hipSuccess) {
         (void)hipGetLastError();
-        if (alt[0]) (void)hipFree(alt[0]);
         return 0; // no room for a second set: keep what there is
     }
-    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipEvent_t &e0 = sc.e0, &e1 = sc.e1;
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
     AsxPeakWs tk = W.pk;
@@ -789,10 +804,9 @@ static int tune_placement(asx_plan *p, const float *d_src, const float *d_smp, s
         }
         p->placement_ms[k] = best;
     }
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
     const int keep = p->placement_ms[1] < 0.995 * p->placement_ms[0] ? 1 : 0;
     p->placement_kept = keep;
+    sc.keep_alt = true; // from here on the loop below owns both sets
     for (int i = 0; i < 2; i++) {
         float2 *drop = set[1 - keep][i];
         auto it = std::find(p->allocs.begin(), p->allocs.end(), (void *)drop);

@@ -139,7 +139,7 @@ struct AsxPeakWs {
 #define ASX_PREP_BLOCKS 4 // blocks of k_pearson_prep that share a pair's window sums on the long tracks (a function of the plan alone)
 #endif
 #define ASX_PREP_BLOCKS_MAX 16 // what the workspaces are sized for
-#define ASX_SPEC_HDR 4    // per pair: r[peak] (plain sum scale), the bound on its error, 1.0 = "the direct reduction, whatever it yields", spare
+#define ASX_SPEC_HDR 4    // per pair: r[peak] (plain sum scale), the bound on its error, 1.0 = "the direct reduction, whatever it yields", the mode k_pearson_partial's block 0 used (read by k_pearson_final_spec)
 // What k_pearson_prep leaves and what reads it: the blocks' SHARES of the four window sums and a header -- no merged record.  The mode of a
 // pair (asx_spec_pick, xcorr_dev.h: a few dozen float64 operations on 4 * nb + 3 numbers) is worked out again by every block of
 // k_pearson_partial and by k_pearson_final_spec: a merge by the last block to arrive cost a device-scope fence per block (28.8 against

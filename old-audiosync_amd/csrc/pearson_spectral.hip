@@ -16,8 +16,9 @@
 //
 // r[peak] is the float32 transforms' value (k_inv_cols_r leaves the SIGNED value of each tile's best lag, AsxPeakWs::tile_peak),
 // or the exact one when the pair's near-ties were re-evaluated (k_refine_dots).  Its error is bounded by the SAME bound B that
-// guards the lag (asx_internal.h); the band sums are float32 sums of 128 terms (a tree: relative error <= 16 eps).  asx_spec_pick
-// (xcorr_dev.h; every block of k_pearson_partial and k_pearson_final_spec runs it on what k_pearson_prep left) turns both into a
+// guards the lag (asx_internal.h); the band sums are float32 sums of 128 - 160 terms: the squares one chain of <= 40 fused multiply-adds
+// (<= 42 u relative), the plain sums a short tree (<= 10 u of sum |x|).  asx_spec_pick (xcorr_dev.h; every block of k_pearson_partial runs
+// it on what k_pearson_prep left, block 0 records the mode for k_pearson_final_spec) turns both into a first-order
 // bound on the coefficient's error and keeps the spectral form only when that bound is below `tol` (1e-5, north_star's tolerance);
 // otherwise -- quiet windows of a loud track, offsets, short segments -- the pair takes the reference's own reduction
 // (k_pearson_partial over the segment, ASX_PM_DIRECT).  Float32 inputs on real-column plans only; the double ABI,
@@ -232,8 +233,9 @@ __global__ __launch_bounds__(64) void k_pearson_final_spec(const AsxSeg *__restr
 {
     const size_t pair = blockIdx.x;
     const AsxSeg s = seg[pair];
-    const AsxSpecPick d = asx_spec_pick(s, S.part + pair * (size_t)(S.nb * 4), S.nb, S.hdr + pair * ASX_SPEC_HDR, S.tol, S.N);
-    const int mode = d.mode;
+    const AsxSpecPick d = asx_spec_pick(s, S.part + pair * (size_t)(S.nb * 4), S.nb, S.hdr + pair * ASX_SPEC_HDR, S.tol, S.N); // the sums
+    // ... and the mode k_pearson_partial's block 0 recorded: the one its blocks wrote the partial sums for (never decided twice)
+    const int mode = (int)S.hdr[pair * ASX_SPEC_HDR + 3];
     PStat v;
     v.n = v.mx = v.my = v.mxx = v.myy = v.cxy = 0.0;
     if (mode != ASX_PM_FAST) { // wave-uniform

@@ -33,6 +33,9 @@
 #include "xcorr_dev.h"
 
 #include <initializer_list>
+#include <map>
+#include <mutex>
+#include <utility>
 #include <stdlib.h>
 
 extern __shared__ __attribute__((aligned(16))) float2 asx_lds_r[];
@@ -641,7 +644,7 @@ __global__ __launch_bounds__(NT, 4) void k_fwd_cols_r(const RArgs P, const float
 // ---------------------------------------------------------------------------
 template <class S1, int TC, int NT>
 __global__ __launch_bounds__(NT, 4) void k_inv_cols_r(const RArgs P, const float2 *__restrict__ qi, size_t pair_pitch,
-                                                       AsxPeakWs W, float *__restrict__ r_out)
+                                                       AsxPeakWs W, float *__restrict__ r_out, unsigned first_gen)
 {
     constexpr int M1 = S1::n, T = TC, logT = asx_ilog2(TC), H = T / 2, logH = logT - 1;
     __shared__ asx_peak_t red[NT / 64];
@@ -667,10 +670,9 @@ __global__ __launch_bounds__(NT, 4) void k_inv_cols_r(const RArgs P, const float
         // The first generation = the blocks resident at once: two per CU for 600- and 400-row tiles, four for 300-row tiles.  (Round 5 had
         // left the 300-row instance alone -- with the FIRST 512 of its 1024 resident blocks treated that way it was 1.5 % slower; with the
         // whole first generation: 0.310 -> 0.278 ms per 1024 pairs of N = 144 000, profiles/r5_experiments/25_*.)
-        constexpr bool TWO_PER_CU = (size_t)M1 * T * 8 > 40 * 1024;
-        constexpr unsigned FIRST_GEN = TWO_PER_CU ? 512u : 1024u;
+        // first_gen comes from the launcher (occupancy of this kernel x the device's CUs: nothing here assumes 256 CUs).
         const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y;
-        if (gridDim.x * gridDim.y > FIRST_GEN && lin < FIRST_GEN && (lin & 1u)) // (a launch of one generation has nobody to inherit the offset)
+        if (gridDim.x * gridDim.y > first_gen && lin < first_gen && (lin & 1u)) // (a launch of one generation has nobody to inherit the offset)
             for (unsigned i = 0; i < (unsigned)(M1 * 27 / 64 / 2); i += 16) __builtin_amdgcn_s_sleep(16); // half a block's life; 64 cycles per unit
     }
     const double shift = W.shift ? W.shift[pair] : 0.0; // non-zero only in the second look (asx_api.hip)
@@ -934,6 +936,26 @@ static void allow_big_lds_r(const void *fn, size_t bytes)
     if (bytes > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
+// Blocks of `fn` the current device holds at once (k_inv_cols_r's first generation, the one its stagger delays half of): occupancy
+// x CUs, asked once per kernel and device.  ADVICE r5: the kernel used to hard-code 512 / 1024 = this part's 256 CUs.
+static unsigned resident_blocks(const void *fn, int nthreads, size_t lds)
+{
+    static std::mutex mu;
+    static std::map<std::pair<const void *, int>, unsigned> known;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = known.find({ fn, dev });
+    if (it != known.end()) return it->second;
+    int per_cu = 0, cus = 0;
+    unsigned n = 512;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, nthreads, lds) == hipSuccess && per_cu > 0 && cus > 0)
+        n = (unsigned)per_cu * (unsigned)cus;
+    known[{ fn, dev }] = n;
+    return n;
+}
+
 bool asx_launch_fwd_cols_r(const AsxDev &P, const float *src, const float *smp, float2 *cx, float2 *cy, const AsxPeakWs &W,
                            int npairs, hipStream_t s)
 {
@@ -960,8 +982,10 @@ bool asx_launch_inv_cols_r(const AsxDev &P, const float2 *q, const AsxPeakWs &W,
     if (P.T == (t) && schedule_is_r(P.st1, m1, { __VA_ARGS__ })) {                               \
         const size_t lds = (size_t)(m1) * (t) * sizeof(float2);                                                             \
         const dim3 grid(npairs, rcol_grid_x(P.M2 / (t), asx_ilog2(t)));                                                     \
-        allow_big_lds_r((const void *)k_inv_cols_r<Sched<m1, __VA_ARGS__>, t, nt>, lds);                                    \
-        hipLaunchKernelGGL((k_inv_cols_r<Sched<m1, __VA_ARGS__>, t, nt>), grid, dim3(nt), lds, s, rargs_of(P), q, pitch, W, r_out); \
+        const void *fn = (const void *)k_inv_cols_r<Sched<m1, __VA_ARGS__>, t, nt>;                                         \
+        allow_big_lds_r(fn, lds);                                                                                           \
+        hipLaunchKernelGGL((k_inv_cols_r<Sched<m1, __VA_ARGS__>, t, nt>), grid, dim3(nt), lds, s, rargs_of(P), q, pitch, W, r_out, \
+                           resident_blocks(fn, nt, lds));                                                                   \
         return true;                                                                                                        \
     }
     ASX_RCOLS(ASX_TRY)

@@ -1044,7 +1044,15 @@ __global__ __launch_bounds__(ASX_THREADS) void k_pearson_partial(const TIn *__re
     AsxSeg s = seg[pair];
     // SPEC (the spectral Pearson form): what this pair still needs read -- nothing, its wrap-around part, or its segment -- follows from
     // the sums k_pearson_prep left; every block works that out for itself (pair-uniform: scalar loads and arithmetic)
-    if constexpr (SPEC) s = asx_spec_pick(s, V.part + pair * (size_t)(V.nb * 4), V.nb, V.hdr + pair * ASX_SPEC_HDR, V.tol, V.N).work;
+    // Block 0 also RECORDS the mode (the spare header slot): k_pearson_final_spec, in another translation unit, reads it instead of
+    // deciding again -- with -ffp-contract=fast two inlining contexts may round `bound <= tol` differently at the threshold, and a final
+    // kernel that disagreed with the work list would read partial sums written for another mode.  One writer, a later
+    // kernel reads: no fence.
+    if constexpr (SPEC) {
+        const AsxSpecPick d = asx_spec_pick(s, V.part + pair * (size_t)(V.nb * 4), V.nb, V.hdr + pair * ASX_SPEC_HDR, V.tol, V.N);
+        s = d.work;
+        if (blockIdx.x == 0 && threadIdx.x == 0) V.hdr[pair * ASX_SPEC_HDR + 3] = (double)d.mode;
+    }
     // gridDim.x partial blocks per pair (asx_pearson_blocks: by the basis length alone); the final kernel merges
     // exactly gridDim.x entries
     const uint32_t chunk = (basis_len + gridDim.x - 1) / gridDim.x;

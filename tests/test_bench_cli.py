@@ -36,6 +36,23 @@ def test_gpus_3_uneven_shards():
     assert line["shards_rank0"]["config4"] == {"total": 8192, "shard": [0, 2731]}
 
 
+def test_per_rank_records_and_a_baseline_line(tmp_path):
+    """the N > 1 line carries every rank's own clock and kernel medians (gathered on the CPU with gloo, the object
+    gather the GPU run uses), and --baseline-json reads an earlier run's line for `speedup_vs`"""
+    base = tmp_path / "one_gpu.json"
+    base.write_text("noise before the line\n" + json.dumps({"n_gpus": 1, "value": 50000.0, "config4": {"value": 160000.0}}) + "\n")
+    p, line = run_bench("--gpus", "3", "--dry-run", "--baseline-json", str(base))
+    assert p.returncode == 0, p.stderr[-2000:]
+    pr = line["per_rank"]
+    assert [r["rank"] for r in pr] == [0, 1, 2]
+    assert [r["ms_per_step"] for r in pr] == [1.0, 2.0, 3.0]
+    assert all(set(r["kernel_ms_per_step"]) >= {"fwd_cols", "rows", "inv_cols", "pearson"} for r in pr)
+    assert sum(r["pairs"] for r in pr) == 18
+    assert line["baseline_seen"] == 1
+    p, line = run_bench("--gpus", "2", "--dry-run", "--baseline-json", str(tmp_path / "missing.json"))
+    assert p.returncode == 0 and line["baseline_seen"] is None
+
+
 def test_a_failing_rank_fails_the_launcher():
     # a rank that cannot form the group (bad backend request) must surface as a non-zero exit code
     p, line = run_bench("--gpus", "2", "--dry-run", env_extra={"ASX_BENCH_DRYRUN_FAIL": "1"})

@@ -149,3 +149,31 @@ def test_double_abi_keeps_the_direct_form(mod):
         ret, lag, coef = plan.xcorr_f64(x, x[1000: 1000 + n].copy())
         assert (ret, lag) == (0, 1000) and coef == 1.0
         assert plan.pearson_modes() == before
+
+
+@pytest.mark.parametrize("n", [144000, 1440000])
+def test_identical_segments_on_the_spectral_path(mod, n):
+    """The ONE observable change the spectral form makes: the reference asserts
+    `coefficient == 1.0` for identical segments (tests/test_cross_correlation.c:29).  The direct form gives exactly +-1.0 -- x and y go
+    through the same operations -- and so do cross_correlation(double*), asx_xcorr_f64 and asx_stream_xcorr, which always reduce directly.
+    The float32 batched entry points of a real-column plan take the cross term from the float32 transforms: there identical (or exactly
+    negated) segments give a coefficient CLAMPED to [-1, 1] and within 1e-5 of +-1.0, not necessarily +-1.0 to the last bit;
+    asx_plan_set_pearson(plan, 0) restores the reference's bits."""
+    rng = np.random.default_rng(n + 5)
+    big = rng.uniform(-1, 1, 2 * n).astype(np.float32)
+    cases = [(0, 1.0), (12345, 1.0), (n - 1, -1.0), (n // 3, -1.0), (-777, 1.0), (-(n // 5), -1.0)]
+    srcs, smps = [], []
+    for lag, sign in cases:
+        smp = (0.25 * rng.uniform(-1, 1, n)).astype(np.float32)       # what lies outside the overlap (negative lags only)
+        if lag >= 0:
+            smp[:] = sign * big[lag: lag + n]
+        else:
+            smp[-lag:] = sign * big[: n + lag]
+        srcs.append(big); smps.append(smp)
+    (lag_s, coef_s, ret_s), (lag_d, coef_d, ret_d), modes = run_both(mod, n, srcs, smps)
+    assert modes[DIRECT] == 0, modes       # every case here is one the spectral form keeps
+    for i, (lag, sign) in enumerate(cases):
+        assert (int(ret_s[i]), int(lag_s[i])) == (0, lag) == (int(ret_d[i]), int(lag_d[i])), (i, lag)
+        assert float(coef_d[i]) == sign, (i, lag, float(coef_d[i]))                       # the reference's exact +-1.0
+        c = float(coef_s[i])
+        assert abs(c) <= 1.0 and 1.0 - abs(c) < COEF_TOL and np.sign(c) == sign, (i, lag, c)

@@ -53,10 +53,24 @@ def disassembly(so_path):
     return out
 
 
+PINNED_ROCM = "7.2"   # the compiler these orders were measured with; another one may order instructions differently without being wrong
+
+
+def rocm_version():
+    try:
+        return open("/opt/rocm/.info/version").read().strip()
+    except OSError:
+        return ""
+
+
 @pytest.fixture(scope="module")
 def isa():
     if not os.path.exists(OBJDUMP):
         pytest.skip("no llvm-objdump in this image")
+    # A SPEED property of the code the pinned compiler emits, not a correctness property: under another ROCm release the
+    # checks below say "re-measure", they must not turn the suite red.
+    if not rocm_version().startswith(PINNED_ROCM):
+        pytest.skip("instruction orders are pinned to ROCm %s (found %r): re-measure profiles/r5_experiments/19-24 there" % (PINNED_ROCM, rocm_version()))
     asx()  # builds the library if it is not there
     d = disassembly(os.path.join(graft.PKG_DIR, "libaudiosync_hip.so"))
     names = subprocess.run(["c++filt"], input="\n".join(d), capture_output=True, text=True).stdout.split("\n")
