@@ -16,8 +16,8 @@
 //
 // r[peak] is the float32 transforms' value (k_inv_cols_r leaves the SIGNED value of each tile's best lag, AsxPeakWs::tile_peak),
 // or the exact one when the pair's near-ties were re-evaluated (k_refine_dots).  Its error is bounded by the SAME bound B that
-// guards the lag (asx_internal.h); the band sums are float32 sums of 128 - 160 terms: the squares one chain of <= 40 fused multiply-adds
-// (<= 42 u relative), the plain sums a short tree (<= 10 u of sum |x|).  asx_spec_pick (xcorr_dev.h; every block of k_pearson_partial runs
+// guards the lag (asx_internal.h); the band sums are float32 sums of 128 - 160 terms: the squares eight fused multiply-adds per row pair and a
+// tree over the pairs (<= 13 u relative), the plain sums a short tree (<= 10 u of sum |x|): both inside the 16 u asx_spec_pick uses.  asx_spec_pick (xcorr_dev.h; every block of k_pearson_partial runs
 // it on what k_pearson_prep left, block 0 records the mode for k_pearson_final_spec) turns both into a first-order
 // bound on the coefficient's error and keeps the spectral form only when that bound is below `tol` (1e-5, north_star's tolerance);
 // otherwise -- quiet windows of a loud track, offsets, short segments -- the pair takes the reference's own reduction

@@ -112,6 +112,17 @@ __device__ __forceinline__ float quad_sum(float v)
     v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true)); // quad_perm [2,3,0,1]
     return v;
 }
+// p[0] + ... + p[N-1] as a balanced tree: ceil(log2 N) roundings on every path
+template <int N> __device__ __forceinline__ float tree_sum(const float (&p)[N])
+{
+    if constexpr (N == 1) return p[0];
+    else {
+        float q[(N + 1) / 2];
+        static_for<0, N / 2>([&](auto I) __attribute__((always_inline)) { q[I] = p[2 * decltype(I)::value] + p[2 * decltype(I)::value + 1]; });
+        if constexpr (N & 1) q[N / 2] = p[N - 1];
+        return tree_sum<(N + 1) / 2>(q);
+    }
+}
 // row pairs a lane group of k_fwd_cols_r<Sched<m1, ...>, t, nt> loads = half the rows of a band (asx_rlayout_band_rows)
 __host__ __device__ constexpr int rcol_rows_per_group(int m1, int nt, int t) { return (m1 + nt / (t / 4) - 1) / (nt / (t / 4)); }
 
@@ -527,6 +538,7 @@ __global__ __launch_bounds__(NT, 4) void k_fwd_cols_r(const RArgs P, const float
     float ss = 0.f, q1 = 0.f;
     {
         float4 a[RPQ], b[RPQ];
+        float sq[RPQ]; // a row pair's eight squares: one chain of eight roundings; the pairs are then added as a tree (below)
         static_for<0, RPQ>([&](auto I) __attribute__((always_inline)) {
             const int m = m0 + decltype(I)::value;
             a[I] = b[I] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -544,10 +556,14 @@ __global__ __launch_bounds__(NT, 4) void k_fwd_cols_r(const RArgs P, const float
                 o[1] = make_float4(a[I].z, b[I].z, a[I].w, b[I].w);
             }
             // (row pairs past the end of the tile or in the sample's zero half hold zeros)
-            ss = fmaf(a[I].x, a[I].x, fmaf(a[I].y, a[I].y, fmaf(a[I].z, a[I].z, fmaf(a[I].w, a[I].w, ss))));
-            ss = fmaf(b[I].x, b[I].x, fmaf(b[I].y, b[I].y, fmaf(b[I].z, b[I].z, fmaf(b[I].w, b[I].w, ss))));
+            sq[I] = fmaf(a[I].x, a[I].x, fmaf(a[I].y, a[I].y, fmaf(a[I].z, a[I].z, a[I].w * a[I].w)));
+            sq[I] = fmaf(b[I].x, b[I].x, fmaf(b[I].y, b[I].y, fmaf(b[I].z, b[I].z, fmaf(b[I].w, b[I].w, sq[I]))));
             if (band) q1 += ((a[I].x + a[I].y) + (a[I].z + a[I].w)) + ((b[I].x + b[I].y) + (b[I].z + b[I].w)); // kernel-uniform
         });
+        // The band's sum of squares feeds the spectral Pearson form's error bound (asx_spec_pick, xcorr_dev.h: <= 16 u relative): eight
+        // roundings per row pair, ceil(log2 RPQ) <= 3 down this tree, two in the quad sum = 13 u.  (Round 5 ran ONE chain through all
+        // RPQ pairs: 8 RPQ + 2 = 42 roundings, which that bound did not cover -- ADVICE r5.)
+        ss = tree_sum<RPQ>(sq);
     }
     if (band) {
         const float r1 = quad_sum(q1), r2 = quad_sum(ss);

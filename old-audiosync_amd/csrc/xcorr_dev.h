@@ -259,15 +259,15 @@ __device__ __forceinline__ AsxSpecPick asx_spec_pick(const AsxSeg s, const doubl
         d.Sx = Sx; d.Sxx = Sxx; d.Sy = Sy; d.Syy = Syy; d.r = hdr[0];
         const double A = Sxx - Sx * Sx / n, B = Syy - Sy * Sy / n;
         if (A > 0.0 && B > 0.0) {
-            // The float32 band sums of k_fwd_cols_r (rlayout.hip), u = 2^-24.  A band's sum of squares is ONE serial chain of 8 RPQ fused
-            // multiply-adds (RPQ <= ASX_RCOL_LOADS = 5 row pairs of 4 + 4 samples) and two DPP additions: <= (8 RPQ + 2) u = 42 u relative
-            // (the 16 u of round 5 was a tree's bound, 2.6 times too small for this chain).  Its plain sum is a tree of depth 3
-            // per row pair, RPQ additions down the pairs and the same two DPP steps: <= (3 + RPQ + 2) u = 10 u of sum|x| <= 10 u sqrt(n Sxx).
-            // The cells are added in float64 (k_pearson_prep).  The bound below is first order in these (products of errors dropped).
-            const double es2 = 42.0 * 5.9604645e-8, es1 = 10.0 * 5.9604645e-8;
-            const double dSx = es1 * sqrt(n * Sxx), dSy = es1 * sqrt(n * Syy);
+            // The float32 band sums of k_fwd_cols_r (rlayout.hip), u = 2^-24.  Sum of squares of a band: eight fused multiply-adds per
+            // row pair, the RPQ <= 5 pairs added as a tree (<= 3 levels), two DPP additions: <= 13 u relative.  Plain sum: a tree of depth 3
+            // per row pair, RPQ additions down the pairs, the same two DPP steps: <= 10 u of sum|x| <= 10 u sqrt(n Sxx).  es = 16 u covers
+            // both (round 5 summed the squares as one chain of 8 RPQ + 2 = 42 roundings, which it did not: ADVICE r5; the kernel changed,
+            // not the constant).  The cells are added in float64 (k_pearson_prep).  First order: products of errors are dropped.
+            const double es = 16.0 * 5.9604645e-8;
+            const double dSx = es * sqrt(n * Sxx), dSy = es * sqrt(n * Syy);
             const double dC = rb + (fabs(Sy) * dSx + fabs(Sx) * dSy) / n;
-            const double dA = es2 * Sxx + 2.0 * fabs(Sx) / n * dSx, dB = es2 * Syy + 2.0 * fabs(Sy) / n * dSy;
+            const double dA = es * Sxx + 2.0 * fabs(Sx) / n * dSx, dB = es * Syy + 2.0 * fabs(Sy) / n * dSy;
             d.bound = dC / sqrt(A * B) + 0.5 * (dA / A + dB / B); // |coefficient| <= 1
             if (d.bound <= tol) {
                 if (s.peak < N) d.mode = ASX_PM_FAST;

@@ -1,4 +1,4 @@
-"""The committed evidence must describe the committed kernels: every profiles/r5_* file that carries a
+"""The committed evidence must describe the committed kernels: every profiles/r6_* file that carries a
 stamp (tools/collect.sh writes `head` and `kernel_commit` into each JSON, and a `# ... kernel commit <hash>` line into
 each CSV / text file) must have been taken at the last commit that touched old-audiosync_amd/csrc.  No GPU needed; skipped
 outside a git checkout (the GPU box gets a snapshot without .git)."""
@@ -11,7 +11,7 @@ import subprocess
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ROUND = 5
+ROUND = 6
 
 
 def git(*args):

@@ -18,8 +18,9 @@ PY
 echo "== traffic + kernel trace, N=1440000"; $R/tools/traffic.sh r${RD}c/traffic_N1440000 > $O/traffic_N1440000.txt 2>&1
 echo "== traffic + kernel trace, N=288000 x 1024"; $R/tools/traffic.sh r${RD}c/traffic_N288000 --sample-len 288000 --batch 1024 > $O/traffic_N288000.txt 2>&1
 echo "== traffic + kernel trace, N=480000 x 1024"; $R/tools/traffic.sh r${RD}c/traffic_N480000 --sample-len 480000 --batch 1024 > $O/traffic_N480000.txt 2>&1
+echo "== traffic + kernel trace, N=720000 x 512"; $R/tools/traffic.sh r${RD}c/traffic_N720000 --sample-len 720000 --batch 512 > $O/traffic_N720000.txt 2>&1
 # the bench lines below quote the PMC traffic of THIS collection (bench.py reads profiles/r<round>_traffic*.json)
-cp $O/traffic_N1440000/traffic.json $R/profiles/r${RD}_traffic.json; cp $O/traffic_N288000/traffic.json $R/profiles/r${RD}_traffic_N288000.json; cp $O/traffic_N480000/traffic.json $R/profiles/r${RD}_traffic_N480000.json
+cp $O/traffic_N1440000/traffic.json $R/profiles/r${RD}_traffic.json; cp $O/traffic_N288000/traffic.json $R/profiles/r${RD}_traffic_N288000.json; cp $O/traffic_N480000/traffic.json $R/profiles/r${RD}_traffic_N480000.json; cp $O/traffic_N720000/traffic.json $R/profiles/r${RD}_traffic_N720000.json
 echo "== bench (headline, cpu baseline, config4, single pair)"; python3 $R/bench.py > $O/bench.json 2> $O/bench.err; stamp $O/bench.json
 for n in 144000 288000 480000 720000 960000; do
   echo "== bench N=$n x 1024"; python3 $R/bench.py --sample-len $n --batch 1024 --steps 20 --no-cpu --no-config4 --no-single > $O/bench_N$n.json 2>> $O/bench.err; stamp $O/bench_N$n.json
