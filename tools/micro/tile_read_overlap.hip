@@ -9,6 +9,7 @@
 //   D   persistent blocks, the next tile's rows sent straight into LDS (global_load_lds_dwordx4, no registers) as soon as the
 //       compute phase has read the tile into registers -- the part of the real kernel that could overlap is its last stage
 //       and scan, ~25 % of a block's life: `tail` = the share of the compute loop that runs behind the DMA issue
+//   E   ONE persistent block per CU with TWO tiles of LDS (153.6 KB): the next tile's DMA runs behind ALL of this tile's compute, at half the waves
 // build + run (GPU box): hipcc --offload-arch=gfx950 -O3 -o /tmp/tile_read_overlap tools/micro/tile_read_overlap.hip && /tmp/tile_read_overlap
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -42,12 +43,12 @@ __device__ __forceinline__ void put(int e, const float4 (&a)[RL], const float4 (
     }
 }
 // `work` rounds of: read 10 slots, 40 x 4 dependent-free fused multiply-adds, write 10 slots (rounds 0 .. work-1; a barrier every `per` rounds)
-__device__ __forceinline__ float compute(int tid, int first, int last, float acc)
+__device__ __forceinline__ float compute(int tid, int first, int last, float acc, float4 *L = lds)
 {
     float4 r[10];
     for (int it = first; it < last; it++) {
 #pragma unroll
-        for (int t = 0; t < 10; t++) r[t] = lds[(tid + t * 480) % 4800];
+        for (int t = 0; t < 10; t++) r[t] = L[(tid + t * 480) % 4800];
 #pragma unroll
         for (int k = 0; k < 12; k++)
 #pragma unroll
@@ -57,7 +58,7 @@ __device__ __forceinline__ float compute(int tid, int first, int last, float acc
             }
         __syncthreads();
 #pragma unroll
-        for (int t = 0; t < 10; t++) { lds[(tid + t * 480) % 4800] = r[t]; acc += r[t].x; }
+        for (int t = 0; t < 10; t++) { L[(tid + t * 480) % 4800] = r[t]; acc += r[t].x; }
         __syncthreads();
     }
     return acc;
@@ -92,6 +93,31 @@ __global__ __launch_bounds__(NT, 4) void k_model(const float4 *__restrict__ q, f
             acc = compute(tid, 0, work, acc);
             if (nxt >= total) break;
             lin = nxt;
+        }
+    } else if (FORM == 3) {
+        // E: ONE block per CU with TWO tiles of LDS: the next tile travels into the other buffer during ALL of this tile's compute
+        unsigned lin = blockIdx.x;
+        if (lin >= total) return;
+        const int lane = tid & 63, wave = tid >> 6;
+        auto dma = [&](unsigned l, float4 *dst) {
+            const unsigned pair = l % npairs, tile = l / npairs;
+            const float4 *src = q + (size_t)pair * (M1 + 1) * PITCH4 + (size_t)tile * 8;
+            for (int r0 = 8 * wave; r0 < M1; r0 += 8 * (NT / 64)) {
+                const float4 *g = src + (size_t)(r0 + (lane >> 3)) * PITCH4 + (lane & 7);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                                 (__attribute__((address_space(3))) void *)(dst + r0 * 8), 16, 0, 0);
+            }
+        };
+        int cur = 0;
+        dma(lin, lds);
+        for (;;) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            const unsigned nxt = lin + gridDim.x;
+            if (nxt < total) dma(nxt, lds + (cur ^ 1) * 4800);
+            acc = compute(tid, 0, work, acc, lds + cur * 4800);
+            if (nxt >= total) break;
+            lin = nxt; cur ^= 1;
         }
     } else {
         // D: rows by LDS-DMA.  Wave w sends rows 8 (w + 8 i) .. + 7 (eight lanes per 128-byte row piece): 1 KiB per instruction, contiguous in LDS
@@ -143,11 +169,11 @@ int main(int argc, char **argv)
     (void)hipMalloc(&q, n4 * 16); (void)hipMalloc(&o, 64); (void)hipMemset(q, 0, n4 * 16);
     const double bytes = (double)n4 * 16;
     hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
-    const size_t ldsb = 76800;
-    const void *fns[3] = { (const void *)k_model<0>, (const void *)k_model<1>, (const void *)k_model<2> };
-    for (const void *f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    const void *fns[4] = { (const void *)k_model<0>, (const void *)k_model<1>, (const void *)k_model<2>, (const void *)k_model<3> };
+    for (const void *f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     auto run = [&](int form, int work, int tail, int stagger) {
         int per_cu = 0;
+        const size_t ldsb = form == 3 ? 2 * 76800 : 76800;
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fns[form], NT, ldsb);
         const unsigned slots = (unsigned)per_cu * 256u, total = (unsigned)pairs * NTILES;
         float best = 1e9f;
@@ -157,6 +183,7 @@ int main(int argc, char **argv)
             if (form == 0) hipLaunchKernelGGL(k_model<0>, dim3(total), dim3(NT), ldsb, 0, q, o, pairs, work, tail, stagger, slots);
             if (form == 1) hipLaunchKernelGGL(k_model<1>, dim3(slots), dim3(NT), ldsb, 0, q, o, pairs, work, tail, stagger, slots);
             if (form == 2) hipLaunchKernelGGL(k_model<2>, dim3(slots), dim3(NT), ldsb, 0, q, o, pairs, work, tail, stagger, slots);
+            if (form == 3) hipLaunchKernelGGL(k_model<3>, dim3(slots), dim3(NT), ldsb, 0, q, o, pairs, work, tail, stagger, slots);
             (void)hipEventRecord(b); (void)hipEventSynchronize(b); (void)hipEventElapsedTime(&ms, a, b);
             if (r >= 1 && ms < best) best = ms;
         }
@@ -171,6 +198,7 @@ int main(int argc, char **argv)
         { "O one-shot", 0, 0, 0 }, { "O one-shot, staggered first generation", 0, 1, 0 },
         { "P persistent, next tile in registers", 1, 0, 0 },
         { "D persistent, LDS-DMA behind the last round (tail 1)", 2, 0, 1 }, { "D persistent, LDS-DMA, tail 2 rounds", 2, 0, 2 },
+        { "E one block per CU, two tiles of LDS, DMA behind everything", 3, 0, 0 },
     };
     for (int rep = 0; rep < 2; rep++)
         for (const Row &R : rows) {
