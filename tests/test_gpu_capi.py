@@ -84,3 +84,10 @@ def test_bench_rank_path_with_the_capi_leg_as_a_child_process():
     d = json.loads(lines[0])
     assert d["results_ok"] and d["world_size_seen"] == 1 and d["config4"]["results_ok"]
     assert d["config4_capi"].get("results_ok") is True and d["config4_capi"]["n_gpus"] == 1, d["config4_capi"]
+    # round 6: the rank's own record (gathered on the CPU with gloo) and the coefficient check of the timed path
+    pr = d["per_rank"]
+    assert len(pr) == 1 and pr[0]["rank"] == 0 and pr[0]["pairs"] > 0 and pr[0]["ms_per_step"] > 0
+    assert set(pr[0]["kernel_ms_per_step"]) >= {"fwd_cols", "rows", "inv_cols", "pearson"} and pr[0]["config4_ms_per_step"] > 0
+    cc = d["coef_check"]
+    assert cc["coef_pairs_compared"] == pr[0]["pairs"] and cc["coef_max_delta"] < cc["coef_tol"], cc
+    assert d["config4"]["coef_check"]["coef_pairs_compared"] == 8192
